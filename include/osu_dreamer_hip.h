@@ -1,0 +1,180 @@
+/* osu_dreamer_hip.h — C ABI of libosudreamer_hip.so (MI355X / gfx950).
+ *
+ * The reference (jaswon/osu-dreamer) has no FFI of its own: its denoiser hot path is
+ * torch op call sites inside osu_dreamer/models/diffusion/{backbone,model,train}.py and
+ * osu_dreamer/common/{attn,swiglu,rms_norm}.py.  Each entry point below replaces one
+ * (group of) those call sites; the citation after "replaces:" is the reference
+ * file:line.  The Python host (osu_dreamer_amd/) binds these with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers (device memory unless stated), ints, floats; the last argument is
+ *    a hipStream_t passed as void*.  Nothing allocates, nothing synchronises.
+ *  - return 0 on success; OD_ERR_* (negative) for argument errors;
+ *    -(hipError_t) - 1000 when the launch itself failed.
+ *  - dtype: OD_F32 or OD_BF16 = element type of activations / packed weights.
+ *    Reductions and accumulators are always fp32; parameter gradients are fp32.
+ *  - "rows" = frames: activations are frame-major [M = B*L][C] with leading dimension
+ *    ld (elements).  Boundary tensors of the reference keep (B, C, L) fp32.
+ */
+#ifndef OSU_DREAMER_HIP_H
+#define OSU_DREAMER_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { OD_F32 = 0, OD_BF16 = 1 };
+enum { OD_EPI_NONE = 0, OD_EPI_SILU = 1 };
+enum { OD_ACT_NONE = 0, OD_ACT_SILU = 1 };
+enum { OD_ERR_ARG = -1, OD_ERR_ALIGN = -2, OD_ERR_UNSUPPORTED = -3 };
+
+int od_version(void);
+const char* od_error_string(int code);
+
+/* ---- GEMMs: every nn.Conv1d(k=1) / nn.Linear on the path ------------------------ */
+/* C[M,N] = epi(A[M,K] W[N,K]^T + bias[N]) (+= old C if accumulate).
+ * replaces: common/attn.py:68-69,75,84; common/swiglu.py:21,25,28,32; backbone.py:63,78;
+ *           model.py:45 (proj_audio), and their autograd backward-data. */
+int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+               int M, int N, int K, int epilogue, int accumulate, void* stream);
+/* dW[N,K] (fp32, ld lddw) += G[M,N]^T A[M,K]   — autograd weight gradient of the above. */
+int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, int M, int N, int K,
+               void* stream);
+/* out[N] (fp32) += column sums of G[M,N]        — autograd bias gradient. */
+int od_colsum(int dtype, const void* G, int ldg, float* out, int M, int N, void* stream);
+/* dst[Np,Kp] (dtype, zero padded) = src[N,K] fp32 (transpose=0) or dst[Kp,Np] = src^T (transpose=1);
+ * row_map: optional int[Np] giving the source row of each destination row (-1 = zero row). */
+int od_pack_weight(int dtype, const float* src, int N, int K, void* dst, int Np, int Kp, int transpose,
+                   const int* row_map, void* stream);
+
+/* ---- small fp32 linears on per-sample vectors (B rows) ---------------------------- */
+/* out[B,N] = act(x[B,K] W[N,K]^T + b).  replaces: model.py:46 (proj_style), backbone.py:76,82
+ * (ssg1/ssg2), model.py:100 (u_mod). */
+int od_linear_small(const float* x, const float* W, const float* b, float* out, float* pre, int B, int N, int K, int act,
+                    void* stream);
+/* given dout[B,N] (gradient wrt the post-activation output) and the forward's pre-activation
+ * `pre` (may be NULL when act == OD_ACT_NONE): dW[N,K] += , db[N] += , dx[B,K] (+)= .
+ * Any of dW/db/dx may be NULL.  dpre[B,N] is fp32 workspace. */
+int od_linear_small_bwd(const float* x, const float* W, const float* pre, const float* dout, float* dpre, float* dW,
+                        float* db, float* dx, int accumulate_dx, int B, int N, int K, int act, void* stream);
+
+/* ---- layout / boundary kernels ------------------------------------------------------ */
+/* (B,C,L) fp32 channel-major -> [B*L][C] frame-major of dtype.  replaces the implicit
+ * layout of audio at model.py:120. */
+int od_cl_to_frames(int dtype, const float* src, void* dst, int ldd, int B, int C, int L, void* stream);
+/* x[m][c] = sum_e W[c][e] xt[b][e][l] + bias[c].  replaces: model.py:95 (proj_in). */
+int od_proj_in(int dtype, const float* xt, const float* W, const float* bias, void* x, int ldx, int B, int E, int L,
+               int D, void* stream);
+/* dW[D,E] += , db[D] += from dx[M][D] and xt. */
+int od_proj_in_bwd(int dtype, const float* xt, const void* dx, int ldx, float* dW, float* db, int B, int E, int L, int D,
+                   void* stream);
+/* y = silu(x) elementwise over [M][C]; dx = dy * silu'(x). */
+int od_silu(int dtype, const void* x, void* y, long n, void* stream);
+int od_silu_bwd(int dtype, const void* x, const void* dy, void* dx, long n, void* stream);
+
+/* ---- channel RMS norm + adaLN modulation (rms_norm at common/rms_norm.py:7-16) ------- */
+/* h = rms_norm(x)*(1+scale[b]) + shift[b] (+ cl[row or row%L]);  inv_rms[m] saved.
+ * ssg: fp32 [B][3C] = scale|shift|gate.  cl may be NULL; cl_bcast=1 when cl has batch 1.
+ * replaces: backbone.py:76-78,82-83. */
+int od_rmsnorm_film(int dtype, const void* x, int ldx, const float* ssg, const void* cl, int ldcl, int cl_bcast,
+                    void* h, int ldh, float* inv_rms, int B, int L, int C, float eps, void* stream);
+/* dres[m] += rms_norm_bwd(dh*(1+scale)); dssg[b][0:C] += sum dh*xhat; dssg[b][C:2C] += sum dh. */
+int od_rmsnorm_film_bwd(int dtype, const void* x, int ldx, const float* inv_rms, const float* ssg, const void* dh,
+                        int lddh, void* dres, int lddres, float* dssg, int B, int L, int C, void* stream);
+/* xo = x + rms_norm(h)*gate[b];  inv_rms[m] saved.  replaces: backbone.py:79-80,85-86. */
+int od_rmsnorm_gate_residual(int dtype, const void* x, int ldx, const void* h, int ldh, const float* ssg, void* xo,
+                             int ldxo, float* inv_rms, int B, int L, int C, float eps, void* stream);
+/* dh = rms_norm_bwd(dy*gate); dssg[b][2C:3C] += sum dy*hhat.  (dy itself is the residual gradient.) */
+int od_rmsnorm_gate_residual_bwd(int dtype, const void* h, int ldh, const float* inv_rms, const float* ssg,
+                                 const void* dy, int lddy, void* dh, int lddh, float* dssg, int B, int L, int C,
+                                 void* stream);
+
+/* ---- attention (common/attn.py:62-84) ------------------------------------------------ */
+/* table[l][j] = (cos, sin)(l * 10000^(-2j/hd)), fp32 [L][hd/2][2].  replaces: attn.py:18-24. */
+int od_rope_table(float* table, int L, int hd, void* stream);
+/* qk_out[m][0:2*dh] = rope(RMSNorm_hd(qkv[m][0:2*dh]) * w) per head.  replaces: attn.py:77-81. */
+int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const float* wq, const float* wk, const float* table,
+                    void* qk_out, int ldo, int B, int L, int H, int hd, float eps, void* stream);
+/* dqkv[m][0:2*dh] from dqk (gradient wrt roped q,k); dwq/dwk[hd] += . */
+int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const float* wq, const float* wk, const float* table,
+                        const void* dqk, int lddqk, void* dqkv, int lddqkv, float* dwq, float* dwk, int B, int L,
+                        int H, int hd, float eps, void* stream);
+/* o[m][h*hd+d] = softmax(q k^T * scale) v, non-causal, per (b,h); lse fp32 [B][H][L].
+ * replaces: attn.py:82 (F.scaled_dot_product_attention). */
+int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
+                      float* lse, int B, int H, int L, int hd, float scale, void* stream);
+/* dq,dk,dv from do; delta fp32 [B][H][L] is workspace. */
+int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                      int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk,
+                      int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, void* stream);
+
+/* ---- SwiGLU feed-forward (common/swiglu.py:9-32) ------------------------------------- */
+/* y[b][l][c] = bias[c] + sum_j w[c][j] x[b][l+j-r][c], zero padded.  replaces: swiglu.py:20, model.py:59,62. */
+int od_dwconv(int dtype, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int L,
+              int C, int ksize, void* stream);
+int od_dwconv_bwd(int dtype, const void* x, int ldx, const float* w, const void* dy, int lddy, void* dx, int lddx,
+                  float* dw, float* db, int B, int L, int C, int ksize, void* stream);
+/* hh[m][0:Hp] = rms_norm_Hf(v*silu(g)), v = vg[m][0:Hp], g = vg[m][Hp:2Hp] (columns >= Hf are zero padding).
+ * replaces: swiglu.py:28-30. */
+int od_swiglu_rmsnorm(int dtype, const void* vg, int ldvg, void* hh, int ldhh, float* inv_rms, int M, int Hf, int Hp,
+                      float eps, void* stream);
+int od_swiglu_rmsnorm_bwd(int dtype, const void* vg, int ldvg, const float* inv_rms, const void* dhh, int lddhh,
+                          void* dvg, int lddvg, int M, int Hf, int Hp, void* stream);
+
+/* ---- heads (models/diffusion/model.py:86-103) ---------------------------------------- */
+/* v[b][e][l] = bias[e] + sum_c W[e][c] rms_norm(x[m])[c]  (fp32, channel-major out).
+ * replaces: backbone.py:50 + model.py:97. */
+int od_final_norm_proj_out(int dtype, const void* x, int ldx, const float* W, const float* bias, float* v,
+                           float* inv_rms, int B, int L, int C, int E, float eps, void* stream);
+int od_final_norm_proj_out_bwd(int dtype, const void* x, int ldx, const float* inv_rms, const float* W, const float* dv,
+                               void* dx, int lddx, float* dW, float* db, int B, int L, int C, int E, void* stream);
+/* fsum[b][c] += sum_l act2[b][c][l] where act2 is the u_head stack applied to xt.  replaces: model.py:58-65,99. */
+int od_uhead_fwd(const float* xt, const float* w0, const float* b0, const float* w1, const float* b1, const float* w3,
+                 const float* b3, const float* w4, const float* b4, float* fsum, int B, int E, int L, int U,
+                 void* stream);
+/* parameter gradients of the stack given dfm[b][c] = dLoss/d(mean_l act2[b][c]). */
+int od_uhead_bwd(const float* xt, const float* w0, const float* b0, const float* w1, const float* b1, const float* w3,
+                 const float* b3, const float* w4, const float* b4, const float* dfm, float* dw0, float* db0, float* dw1,
+                 float* db1, float* dw3, float* db3, float* dw4, float* db4, int B, int E, int L, int U, void* stream);
+/* u[b] = u_scale*softplus(w_out . (f*(1+mod[0:U]) + mod[U:2U]) + b_out), f = fsum/L.  replaces: model.py:100-102. */
+int od_uhead_tail(const float* fsum, const float* mod, const float* w_out, const float* b_out, float* u, int B, int U,
+                  int L, float u_scale, void* stream);
+/* backward of the tail: dfm[b][c], dmod[b][2U], dw_out[U] +=, db_out[1] += from du[b]. */
+int od_uhead_tail_bwd(const float* fsum, const float* mod, const float* w_out, const float* b_out, const float* du,
+                      float* dfm, float* dmod, float* dw_out, float* db_out, int B, int U, int L, float u_scale,
+                      void* stream);
+
+/* ---- diffusion loss + sampler (models/diffusion/train.py:69-108, model.py:117-138) -- */
+/* xt = lerp(x0,x1,t[b]); dsq[b] = frame_dist_sq(xt,x1).  (dsq must be zeroed by the caller.) */
+int od_make_xt(const float* x0, const float* x1, const float* t, float* xt, float* dsq, int B, int E, int L, void* stream);
+/* sums[b][0..2] += (S1, S2, dS1/du) ; dv = dLoss/dv_pred.  Needs dsq complete. */
+int od_loss_grad(const float* xt, const float* x1, const float* u, const float* v, const float* dsq, float* dv,
+                 float* sums, int B, int E, int L, float c0, float osl_w, float del_w, void* stream);
+/* out[0..3] = loss, osl, del, u_mape; du[b] = dLoss/du_pred. */
+int od_loss_finalize(const float* sums, const float* dsq, const float* u, float* out, float* du, int B, float c0,
+                     float osl_w, float del_w, void* stream);
+/* x -= eta[0] * u[b] * v  (eta is a device scalar so the step is graph-capturable).  replaces: model.py:136. */
+int od_sampler_step(float* x, const float* u, const float* v, const float* eta, int B, int E, int L, void* stream);
+/* eta[0] = 1 - (sqrt(c0)/max(mean(u), sqrt(c0)+1e-6))^(1/num_steps); also eta[1] = mean(u).  replaces: model.py:131-132. */
+int od_sampler_eta(const float* u, float* eta, int B, float c0, int num_steps, void* stream);
+
+/* ---- optimizer (models/diffusion/train.py:110-126; model.yml:39) --------------------- */
+/* out[0] += sum g^2. */
+int od_sqnorm(const float* g, long n, float* out, void* stream);
+/* clip by global norm (gnorm_sq device scalar, max_norm<=0 disables) -> AdamW -> EMA, one pass.
+ * ema_mode: 0 none, 1 copy (first update), 2 lerp with (1-ema_decay). */
+int od_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float ema_decay, int ema_mode, const float* gnorm_sq,
+                 float max_norm, void* stream);
+
+/* ---- hipGraph helpers for the captured sampler loop ---------------------------------- */
+int od_graph_begin(void* stream);
+int od_graph_end(void* stream, void** graph_exec_out);
+int od_graph_launch(void* graph_exec, void* stream);
+int od_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

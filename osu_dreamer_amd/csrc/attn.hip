@@ -1,0 +1,552 @@
+// Flash attention for the denoiser's non-causal self-attention (common/attn.py:82,
+// F.scaled_dot_product_attention) — forward, and backward as two kernels (dK/dV owned by
+// key tiles, dQ owned by query tiles; no atomics, deterministic).
+//
+// Layout: q/k/v/o are frame-major rows with heads as 64-feature column groups:
+//   element (b, h, l, d) at base[(b*L + l)*ld + h*HD + d].
+//
+// MFMA formulation (16x16 tiles, 32-deep K slabs, od_frag<T>): every product is arranged
+// so that the softmax row index is the accumulator COLUMN (lane&15).  Then the running max,
+// the running sum, LSE and delta are lane-local scalars, and a C-layout score tile is
+// directly the B (or A) operand of the next MFMA with the key permutation
+//     k-slot j of lane-group g  <->  index 32u + 16*(j>>2) + 4g + (j&3),
+// which the other operand reproduces by reading a TRANSPOSED LDS tile with two half-width
+// reads.  fwd:  S^T = K Q^T ;  O^T += V^T P^T.
+#include "od_common.h"
+#include "od_api_internal.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_BIG = -1.0e30f;
+
+// ---- swizzled LDS tile addressing: 16-byte slots XORed with the row index ---------------
+template <int ROWB>
+__device__ __forceinline__ int tile_off(int row, int byte) {
+    constexpr int NS = ROWB / 16;
+    return row * ROWB + ((((byte >> 4)) ^ (row & (NS - 1))) << 4) + (byte & 15);
+}
+
+// 8 k-contiguous elements of `row` starting at element k0 (multiple of 8)
+template <int ROWB>
+__device__ __forceinline__ void frag_contig(od_frag<bf16_t>& f, const unsigned char* t, int row, int k0) {
+    f.v = *(const s16x8*)(t + tile_off<ROWB>(row, k0 * 2));
+}
+template <int ROWB>
+__device__ __forceinline__ void frag_contig(od_frag<float>& f, const unsigned char* t, int row, int k0) {
+    const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4));
+    const f32x4 b = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4 + 16));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+// permuted slab u: elements {32u+4g .. +3} and {32u+16+4g .. +3} of `row`
+template <int ROWB>
+__device__ __forceinline__ void frag_perm(od_frag<bf16_t>& f, const unsigned char* t, int row, int u, int g) {
+    const s16x4 a = *(const s16x4*)(t + tile_off<ROWB>(row, (32 * u + 4 * g) * 2));
+    const s16x4 b = *(const s16x4*)(t + tile_off<ROWB>(row, (32 * u + 16 + 4 * g) * 2));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+template <int ROWB>
+__device__ __forceinline__ void frag_perm(od_frag<float>& f, const unsigned char* t, int row, int u, int g) {
+    const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, (32 * u + 4 * g) * 4));
+    const f32x4 b = *(const f32x4*)(t + tile_off<ROWB>(row, (32 * u + 16 + 4 * g) * 4));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+
+// ---- staging a [64 rows][HD] global tile through registers -------------------------------
+template <class T, int HD>
+struct Stage {
+    static constexpr int ROWB = HD * (int)sizeof(T);        // row-major tile row bytes
+    static constexpr int TROWB = 64 * (int)sizeof(T);       // transposed tile row bytes
+    static constexpr int CPR = ROWB / 16;                   // 16-byte chunks per row
+    static constexpr int NCH = 64 * CPR / 256;              // chunks per thread
+    static constexpr int EPC = 16 / (int)sizeof(T);         // elements per chunk
+    static constexpr int BYTES = 64 * ROWB;                 // == HD * TROWB
+    u32x4 r[NCH];
+
+    // rows row0..row0+63 of a (rows x HD) strip; rows >= nrows are clamped (caller masks)
+    __device__ __forceinline__ void load(const T* base, int ld, int row0, int nrows) {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = threadIdx.x + 256 * i, row = c / CPR, ch = c % CPR;
+            int gr = row0 + row; gr = gr < nrows ? gr : nrows - 1;
+            r[i] = *(const u32x4*)(base + (size_t)gr * ld + ch * EPC);
+        }
+    }
+    __device__ __forceinline__ void store_rowmajor(unsigned char* t) const {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = threadIdx.x + 256 * i, row = c / CPR, ch = c % CPR;
+            *(u32x4*)(t + tile_off<ROWB>(row, ch * 16)) = r[i];
+        }
+    }
+    // element (row, col) -> transposed tile row `col`, position `row`
+    __device__ __forceinline__ void store_transposed(unsigned char* t) const {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = threadIdx.x + 256 * i, row = c / CPR, ch = c % CPR;
+            const T* p = (const T*)&r[i];
+#pragma unroll
+            for (int e = 0; e < EPC; e++) *(T*)(t + tile_off<TROWB>(ch * EPC + e, row * (int)sizeof(T))) = p[e];
+        }
+    }
+};
+
+// XCD-aware (b,h)/tile order: all tiles of one (b,h) run on one XCD so K/V (or Q/dO) stay in its L2
+__device__ __forceinline__ bool attn_block_coords(int ntiles, int BH, int& tile, int& bh) {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    bh = (slot / ntiles) * 8 + xcd;
+    tile = slot % ntiles;
+    return bh < BH;
+}
+inline int attn_grid(int ntiles, int BH) { return ((BH + 7) / 8) * 8 * ntiles; }
+
+// store 4 consecutive features
+__device__ __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
+    u32x2 v;
+    v[0] = (uint32_t)od_f2bf(a) | ((uint32_t)od_f2bf(b) << 16);
+    v[1] = (uint32_t)od_f2bf(c) | ((uint32_t)od_f2bf(d) << 16);
+    *(u32x2*)p = v;
+}
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
+    f32x4 v; v[0] = a; v[1] = b; v[2] = c; v[3] = d;
+    *(f32x4*)p = v;
+}
+
+// ======================================================================== forward
+// block: 4 waves x 32 query rows; loop over 64-key tiles.
+template <class T, int HD>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                                        const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
+                                                        float* __restrict__ lse, int B, int H, int L, float scale) {
+    using St = Stage<T, HD>;
+    constexpr int NS = HD / 32;   // 32-deep slabs over the head dim
+    constexpr int ND = HD / 16;   // 16-row tiles over the head dim
+    OD_DYN_SMEM(smem);   // 4 * St::BYTES : 2 stages x (K, V^T)
+    const int nqt = (L + 127) / 128;
+    int qt, bh;
+    if (!attn_block_coords(nqt, B * H, qt, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const T* qb = q + (size_t)b * L * ldq + h * HD;
+    const T* kb = k + (size_t)b * L * ldk + h * HD;
+    const T* vb = v + (size_t)b * L * ldv + h * HD;
+    const int q0 = qt * 128 + wave * 32;
+    const float c = scale * LOG2E;
+
+    od_frag<T> fq[2][NS];
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+        int row = q0 + qi * 16 + x; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s = 0; s < NS; s++) od_frag_load(fq[qi][s], qb + (size_t)row * ldq + s * 32 + g * 8);
+    }
+    f32x4 oacc[2][ND];
+    float mrun[2], lrun[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+        mrun[qi] = NEG_BIG; lrun[qi] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++) oacc[qi][dt] = (f32x4)(0.f);
+    }
+
+    const int nkt = (L + 63) / 64;
+    St sk, sv;
+    sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L);
+    sk.store_rowmajor(smem); sv.store_transposed(smem + St::BYTES);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+        const unsigned char* tK = smem + (kt & 1) * 2 * St::BYTES;
+        const unsigned char* tV = tK + St::BYTES;
+        if (kt + 1 < nkt) { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
+
+        // S^T tiles: rows = keys (4 tiles of 16), cols = queries
+        f32x4 sacc[2][4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; t4++) {
+            od_frag<T> fk[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) frag_contig<St::ROWB>(fk[s], tK, t4 * 16 + x, s * 32 + g * 8);
+#pragma unroll
+            for (int qi = 0; qi < 2; qi++) {
+                f32x4 a = (f32x4)(0.f);
+#pragma unroll
+                for (int s = 0; s < NS; s++) a = od_mma(fk[s], fq[qi][s], a);
+                sacc[qi][t4] = a;
+            }
+        }
+        // online softmax; lane owns query column x, keys 16*t4 + 4g + r
+        od_frag<T> fp[2][2];
+        const int kbase = kt * 64;
+#pragma unroll
+        for (int qi = 0; qi < 2; qi++) {
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float sv_ = sacc[qi][t4][r] * c;
+                    if (kbase + t4 * 16 + 4 * g + r >= L) sv_ = NEG_BIG;
+                    sacc[qi][t4][r] = sv_;
+                    mx = fmaxf(mx, sv_);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[qi], mx);
+            const float alpha = exp2f(mrun[qi] - mnew);
+            mrun[qi] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float p = exp2f(sacc[qi][t4][r] - mnew);
+                    ps += p;
+                    od_frag_set(fp[qi][t4 >> 1], (t4 & 1) * 4 + r, p);
+                }
+            lrun[qi] = lrun[qi] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++) oacc[qi][dt] *= alpha;
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                od_frag<T> fv;
+                frag_perm<St::TROWB>(fv, tV, dt * 16 + x, u, g);
+#pragma unroll
+                for (int qi = 0; qi < 2; qi++) oacc[qi][dt] = od_mma(fv, fp[qi][u], oacc[qi][dt]);
+            }
+        if (kt + 1 < nkt) {
+            unsigned char* nK = smem + ((kt + 1) & 1) * 2 * St::BYTES;
+            sk.store_rowmajor(nK); sv.store_transposed(nK + St::BYTES);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+        float l = lrun[qi];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.f / l;
+        const int row = q0 + qi * 16 + x;
+        if (row < L) {
+            T* orow = o + ((size_t)b * L + row) * ldo + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++)
+                st4(orow + dt * 16 + 4 * g, oacc[qi][dt][0] * inv, oacc[qi][dt][1] * inv, oacc[qi][dt][2] * inv, oacc[qi][dt][3] * inv);
+            if (g == 0) lse[((size_t)b * H + h) * L + row] = (mrun[qi] + log2f(l)) * LN2;
+        }
+    }
+}
+
+// ======================================================================== backward
+// delta[b][h][l] = sum_d dO*O  — one wave per frame row, lanes over (h, d) chunks of 8
+template <class T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, int ldo, const T* __restrict__ dout, int lddo,
+                                                         float* __restrict__ delta, int B, int H, int L, int HD) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)B * L) return;
+    const int b = (int)(m / L), l = (int)(m % L);
+    const int lph = HD / 8, nch = H * lph;
+    for (int it = 0; it * 64 < nch; it++) {
+        const int qd = it * 64 + lane;
+        const bool act = qd < nch;
+        float s = 0.f;
+        if (act) {
+            float a[8], d[8];
+            od_ld8(o + m * ldo + qd * 8, a); od_ld8(dout + m * lddo + qd * 8, d);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += a[e] * d[e];
+        }
+        for (int msk = 1; msk < lph; msk <<= 1) s += __shfl_xor(s, msk);
+        if (act && (qd % lph) == 0) delta[((size_t)b * H + qd / lph) * L + l] = s;
+    }
+}
+
+// dK, dV: block owns 4 waves x NK*16 keys; loop over 64-query tiles.
+//   S = Q K^T (cols = keys) ; dV^T += dO^T P ; dP = dO V^T ; dS = P*(dP - delta)*scale ; dK^T += Q^T dS
+template <class T, int HD, int NK>
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                                            const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            T* __restrict__ dk, int lddk, T* __restrict__ dv, int lddv,
+                                                            int B, int H, int L, float scale) {
+    using St = Stage<T, HD>;
+    constexpr int NS = HD / 32, ND = HD / 16, KB = 4 * NK * 16;
+    OD_DYN_SMEM(smem);   // 4 * St::BYTES (Q, Q^T, dO, dO^T) + 512 B (lse, delta)
+    float* s_lse = (float*)(smem + 4 * St::BYTES);
+    float* s_delta = s_lse + 64;
+    const int nkt = (L + KB - 1) / KB;
+    int ktile, bh;
+    if (!attn_block_coords(nkt, B * H, ktile, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const T* qb = q + (size_t)b * L * ldq + h * HD;
+    const T* kb = k + (size_t)b * L * ldk + h * HD;
+    const T* vb = v + (size_t)b * L * ldv + h * HD;
+    const T* dob = dout + (size_t)b * L * lddo + h * HD;
+    const float* lseb = lse + ((size_t)b * H + h) * L;
+    const float* delb = delta + ((size_t)b * H + h) * L;
+    const int key0 = ktile * KB + wave * NK * 16;
+    const float c = scale * LOG2E;
+
+    od_frag<T> fk[NK][NS], fv[NK][NS];
+#pragma unroll
+    for (int ki = 0; ki < NK; ki++) {
+        int row = key0 + ki * 16 + x; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            od_frag_load(fk[ki][s], kb + (size_t)row * ldk + s * 32 + g * 8);
+            od_frag_load(fv[ki][s], vb + (size_t)row * ldv + s * 32 + g * 8);
+        }
+    }
+    f32x4 dkacc[NK][ND], dvacc[NK][ND];
+#pragma unroll
+    for (int ki = 0; ki < NK; ki++)
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++) { dkacc[ki][dt] = (f32x4)(0.f); dvacc[ki][dt] = (f32x4)(0.f); }
+
+    unsigned char* tQ = smem;
+    unsigned char* tQT = smem + St::BYTES;
+    unsigned char* tO = smem + 2 * St::BYTES;
+    unsigned char* tOT = smem + 3 * St::BYTES;
+    const int nqt = (L + 63) / 64;
+    St sq, so;
+    float r_lse = 0.f, r_del = 0.f;
+    auto gload = [&](int qt) {
+        sq.load(qb, ldq, qt * 64, L); so.load(dob, lddo, qt * 64, L);
+        if (threadIdx.x < 64) {
+            const int row = qt * 64 + threadIdx.x;
+            r_lse = row < L ? lseb[row] : 0.f;
+            r_del = row < L ? delb[row] : 0.f;
+        }
+    };
+    auto lstore = [&]() {
+        sq.store_rowmajor(tQ); sq.store_transposed(tQT); so.store_rowmajor(tO); so.store_transposed(tOT);
+        if (threadIdx.x < 64) { s_lse[threadIdx.x] = r_lse * LOG2E; s_delta[threadIdx.x] = r_del; }
+    };
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int qt = 0; qt < nqt; qt++) {
+        if (qt + 1 < nqt) gload(qt + 1);
+        const int qbase = qt * 64;
+        // per 32-query slab u (two 16-row tiles): scores, probabilities, dP, dS
+        od_frag<T> fp[NK][2], fds[NK][2];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; t4++) {
+            od_frag<T> fqr[NS], fdo[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                frag_contig<St::ROWB>(fqr[s], tQ, t4 * 16 + x, s * 32 + g * 8);
+                frag_contig<St::ROWB>(fdo[s], tO, t4 * 16 + x, s * 32 + g * 8);
+            }
+            const f32x4 l4 = *(const f32x4*)(s_lse + t4 * 16 + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(s_delta + t4 * 16 + 4 * g);
+#pragma unroll
+            for (int ki = 0; ki < NK; ki++) {
+                f32x4 sa = (f32x4)(0.f), pa = (f32x4)(0.f);
+#pragma unroll
+                for (int s = 0; s < NS; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
+                const bool kvalid = key0 + ki * 16 + x < L;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool valid = kvalid && (qbase + t4 * 16 + 4 * g + r < L);
+                    const float p = valid ? exp2f(sa[r] * c - l4[r]) : 0.f;
+                    const float ds = p * (pa[r] - d4[r]) * scale;
+                    od_frag_set(fp[ki][t4 >> 1], (t4 & 1) * 4 + r, p);
+                    od_frag_set(fds[ki][t4 >> 1], (t4 & 1) * 4 + r, ds);
+                }
+            }
+        }
+        // dV^T += dO^T P ; dK^T += Q^T dS     (A rows = features, k = permuted queries, cols = keys)
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                od_frag<T> fot, fqt;
+                frag_perm<St::TROWB>(fot, tOT, dt * 16 + x, u, g);
+                frag_perm<St::TROWB>(fqt, tQT, dt * 16 + x, u, g);
+#pragma unroll
+                for (int ki = 0; ki < NK; ki++) {
+                    dvacc[ki][dt] = od_mma(fot, fp[ki][u], dvacc[ki][dt]);
+                    dkacc[ki][dt] = od_mma(fqt, fds[ki][u], dkacc[ki][dt]);
+                }
+            }
+        __syncthreads();
+        if (qt + 1 < nqt) lstore();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ki = 0; ki < NK; ki++) {
+        const int row = key0 + ki * 16 + x;
+        if (row < L) {
+            T* dkr = dk + ((size_t)b * L + row) * lddk + h * HD;
+            T* dvr = dv + ((size_t)b * L + row) * lddv + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++) {
+                st4(dkr + dt * 16 + 4 * g, dkacc[ki][dt][0], dkacc[ki][dt][1], dkacc[ki][dt][2], dkacc[ki][dt][3]);
+                st4(dvr + dt * 16 + 4 * g, dvacc[ki][dt][0], dvacc[ki][dt][1], dvacc[ki][dt][2], dvacc[ki][dt][3]);
+            }
+        }
+    }
+}
+
+// dQ: block owns 4 waves x NQ*16 queries; loop over 64-key tiles.
+//   S^T = K Q^T ; dP^T = V dO^T ; dS^T = P^T*(dP^T - delta)*scale ; dQ^T += K^T dS^T
+template <class T, int HD, int NQ>
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                                           const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           T* __restrict__ dq, int lddq, int B, int H, int L, float scale) {
+    using St = Stage<T, HD>;
+    constexpr int NS = HD / 32, ND = HD / 16, QB = 4 * NQ * 16;
+    OD_DYN_SMEM(smem);   // 3 * St::BYTES : K, K^T, V
+    const int nqt = (L + QB - 1) / QB;
+    int qtile, bh;
+    if (!attn_block_coords(nqt, B * H, qtile, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const T* qb = q + (size_t)b * L * ldq + h * HD;
+    const T* kb = k + (size_t)b * L * ldk + h * HD;
+    const T* vb = v + (size_t)b * L * ldv + h * HD;
+    const T* dob = dout + (size_t)b * L * lddo + h * HD;
+    const int q0 = qtile * QB + wave * NQ * 16;
+    const float c = scale * LOG2E;
+
+    od_frag<T> fq[NQ][NS], fdo[NQ][NS];
+    float r_lse[NQ], r_del[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; qi++) {
+        int row = q0 + qi * 16 + x; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            od_frag_load(fq[qi][s], qb + (size_t)row * ldq + s * 32 + g * 8);
+            od_frag_load(fdo[qi][s], dob + (size_t)row * lddo + s * 32 + g * 8);
+        }
+        r_lse[qi] = lse[((size_t)b * H + h) * L + row] * LOG2E;
+        r_del[qi] = delta[((size_t)b * H + h) * L + row];
+    }
+    f32x4 dqacc[NQ][ND];
+#pragma unroll
+    for (int qi = 0; qi < NQ; qi++)
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++) dqacc[qi][dt] = (f32x4)(0.f);
+
+    unsigned char* tK = smem;
+    unsigned char* tKT = smem + St::BYTES;
+    unsigned char* tV = smem + 2 * St::BYTES;
+    const int nkt = (L + 63) / 64;
+    St sk, sv;
+    sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L);
+    sk.store_rowmajor(tK); sk.store_transposed(tKT); sv.store_rowmajor(tV);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+        if (kt + 1 < nkt) { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
+        const int kbase = kt * 64;
+        od_frag<T> fds[NQ][2];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; t4++) {
+            od_frag<T> fkr[NS], fvr[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                frag_contig<St::ROWB>(fkr[s], tK, t4 * 16 + x, s * 32 + g * 8);
+                frag_contig<St::ROWB>(fvr[s], tV, t4 * 16 + x, s * 32 + g * 8);
+            }
+#pragma unroll
+            for (int qi = 0; qi < NQ; qi++) {
+                f32x4 sa = (f32x4)(0.f), pa = (f32x4)(0.f);
+#pragma unroll
+                for (int s = 0; s < NS; s++) { sa = od_mma(fkr[s], fq[qi][s], sa); pa = od_mma(fvr[s], fdo[qi][s], pa); }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool valid = kbase + t4 * 16 + 4 * g + r < L;
+                    const float p = valid ? exp2f(sa[r] * c - r_lse[qi]) : 0.f;
+                    od_frag_set(fds[qi][t4 >> 1], (t4 & 1) * 4 + r, p * (pa[r] - r_del[qi]) * scale);
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                od_frag<T> fkt;
+                frag_perm<St::TROWB>(fkt, tKT, dt * 16 + x, u, g);
+#pragma unroll
+                for (int qi = 0; qi < NQ; qi++) dqacc[qi][dt] = od_mma(fkt, fds[qi][u], dqacc[qi][dt]);
+            }
+        __syncthreads();
+        if (kt + 1 < nkt) { sk.store_rowmajor(tK); sk.store_transposed(tKT); sv.store_rowmajor(tV); }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qi = 0; qi < NQ; qi++) {
+        const int row = q0 + qi * 16 + x;
+        if (row < L) {
+            T* dqr = dq + ((size_t)b * L + row) * lddq + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++)
+                st4(dqr + dt * 16 + 4 * g, dqacc[qi][dt][0], dqacc[qi][dt][1], dqacc[qi][dt][2], dqacc[qi][dt][3]);
+        }
+    }
+}
+
+template <class T, int HD>
+int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* lse, int B,
+               int H, int L, float scale, hipStream_t st) {
+    const int grid = attn_grid((L + 127) / 128, B * H);
+    OD_LAUNCH_DYN((flash_fwd_kernel<T, HD>), dim3(grid), dim3(256), (4 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+              (T*)o, ldo, lse, B, H, L, scale);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+template <class T, int HD, int NK, int NQ>
+int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout,
+               int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H,
+               int L, float scale, hipStream_t st) {
+    const long M = (long)B * L;
+    OD_LAUNCH((attn_delta_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)o, ldo, (const T*)dout, lddo, delta,
+              B, H, L, HD);
+    const int gk = attn_grid((L + 64 * NK - 1) / (64 * NK), B * H);
+    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK>), dim3(gk), dim3(256), (4 * Stage<T, HD>::BYTES + 512), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+              (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale);
+    const int gq = attn_grid((L + 64 * NQ - 1) / (64 * NQ), B * H);
+    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ>), dim3(gq), dim3(256), (3 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+              (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
+                                 int ldo, float* lse, int B, int H, int L, int hd, float scale, void* stream) {
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return OD_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OD_BF16 && hd == 64) return launch_fwd<bf16_t, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
+    if (dtype == OD_BF16 && hd == 32) return launch_fwd<bf16_t, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
+    if (dtype == OD_F32 && hd == 64) return launch_fwd<float, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
+    if (dtype == OD_F32 && hd == 32) return launch_fwd<float, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
+    return OD_ERR_UNSUPPORTED;
+}
+
+extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                                 int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq,
+                                 void* dk, int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, void* stream) {
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+#define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st
+    if (dtype == OD_BF16 && hd == 64) return launch_bwd<bf16_t, 64, 2, 2>(ARGS);
+    if (dtype == OD_BF16 && hd == 32) return launch_bwd<bf16_t, 32, 2, 2>(ARGS);
+    if (dtype == OD_F32 && hd == 64) return launch_bwd<float, 64, 1, 1>(ARGS);
+    if (dtype == OD_F32 && hd == 32) return launch_bwd<float, 32, 1, 1>(ARGS);
+#undef ARGS
+    return OD_ERR_UNSUPPORTED;
+}

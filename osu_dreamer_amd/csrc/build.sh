@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libosudreamer_hip.so for gfx950 (in-tree; the .so travels to the GPU box with the snapshot).
+set -e
+cd "$(dirname "$0")"
+OUT=../libosudreamer_hip.so
+SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip"
+OBJS=""
+mkdir -p build
+for s in $SRCS; do
+  o=build/${s%.hip}.o
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ od_common.h -nt "$o" ] || [ ../../include/osu_dreamer_hip.h -nt "$o" ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" ${OD_HIPCC_FLAGS} &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
+echo "built $OUT"

@@ -1,0 +1,331 @@
+// MFMA GEMMs for the denoiser's 1x1 Conv1d / Linear layers (frame-major rows).
+//
+//   NT : C[M,N]  = epi(A[M,K] · W[N,K]^T + bias)       forward and backward-data
+//   TN : dW[N,K] += G[M,N]^T · A[M,K]                  backward-weight (fp32, split-M)
+//
+// Replaces the torch ops at the reference's nn.Conv1d(k=1)/nn.Linear call sites
+// (common/attn.py:68-69, common/swiglu.py:21,25, models/diffusion/backbone.py:63,
+// models/diffusion/model.py:45-50).  128x128 block tile, 4 waves each owning 64x64
+// (4x4 MFMA 16x16 tiles), 128-byte K slabs double-buffered in LDS with a 16-byte-slot
+// XOR swizzle, register-staged prefetch of the next slab under the MFMAs, and an
+// epilogue staged through LDS so global stores are 16/32-byte rows.
+#include "od_common.h"
+#include "od_api_internal.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int STAGE_BYTES = 32768;  // A 16 KiB + B 16 KiB
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 128 + (((slot) ^ (row & 7)) << 4); }
+
+template <class T>
+__device__ __forceinline__ void frag_from_lds(od_frag<T>& f, const unsigned char* tile, int row, int slab, int g);
+template <>
+__device__ __forceinline__ void frag_from_lds<bf16_t>(od_frag<bf16_t>& f, const unsigned char* tile, int row, int slab, int g) {
+    f.v = *(const s16x8*)(tile + swz(row, slab * 4 + g));
+}
+template <>
+__device__ __forceinline__ void frag_from_lds<float>(od_frag<float>& f, const unsigned char* tile, int row, int slab, int g) {
+    f32x4 a = *(const f32x4*)(tile + swz(row, slab * 8 + 2 * g));
+    f32x4 b = *(const f32x4*)(tile + swz(row, slab * 8 + 2 * g + 1));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+
+// One 128-byte-deep slab of MFMAs from a staged (A,B) pair.
+template <class T>
+__device__ __forceinline__ void compute_stage(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
+                                              f32x4 (&acc)[4][4]) {
+    constexpr int SLABS = (128 / (int)sizeof(T)) / 32;
+    const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < SLABS; s++) {
+        od_frag<T> fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) frag_from_lds<T>(fa[i], sA, wm * 64 + i * 16 + r16, s, g);
+#pragma unroll
+        for (int j = 0; j < 4; j++) frag_from_lds<T>(fb[j], sB, wn * 64 + j * 16 + r16, s, g);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = od_mma(fa[i], fb[j], acc[i][j]);
+    }
+}
+
+// XCD-aware tile order: block b runs on XCD b%8 (observed dispatch); each XCD walks
+// its own row-tiles with the column tile fastest so an A row-panel is fetched from
+// HBM once and re-read from that XCD's L2 by the other column tiles.
+__device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    tm = (slot / tiles_n) * 8 + xcd;
+    tn = slot % tiles_n;
+    return tm < tiles_m;
+}
+
+template <class T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                      const float* __restrict__ bias, T* __restrict__ C, int ldc,
+                                                      int M, int N, int K, int accumulate) {
+    constexpr int BK = 128 / (int)sizeof(T);  // elements per slab row
+    constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    int tm, tn;
+    if (!tile_of_block(tiles_m, tiles_n, tm, tn)) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4)(0.f);
+
+    u32x4 ra[4], rb[4];
+    const int nk = (K + BK - 1) / BK;
+
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
+            const int k = kt * BK + slot * CH;
+            int ar = m0 + row; ar = ar < M ? ar : M - 1;
+            int br = n0 + row; br = br < N ? br : N - 1;
+            if (k < K) {
+                ra[i] = *(const u32x4*)(A + (size_t)ar * lda + k);
+                rb[i] = *(const u32x4*)(W + (size_t)br * ldw + k);
+            } else {
+                ra[i] = (u32x4)(0u); rb[i] = (u32x4)(0u);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* sA = smem + buf * STAGE_BYTES;
+        unsigned char* sB = sA + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
+            *(u32x4*)(sA + swz(row, slot)) = ra[i];
+            *(u32x4*)(sB + swz(row, slot)) = rb[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        compute_stage<T>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: accumulators -> LDS (f32 [128][128]) -> coalesced row stores
+    float* sC = (float*)smem;
+    {
+        const int col = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    sC[(wm * 64 + i * 16 + g * 4 + r) * 128 + wn * 64 + j * 16 + col] = acc[i][j][r];
+    }
+    __syncthreads();
+    const bool vec_ok = (N % 8 == 0) && (ldc % 8 == 0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+        const int gm = m0 + row, gn = n0 + ch * 8;
+        if (gm >= M || gn >= N) continue;
+        float v[8];
+        od_ld8(sC + row * 128 + ch * 8, v);
+        T* dst = C + (size_t)gm * ldc + gn;
+        if (vec_ok) {
+            if (bias) {
+                float bv[8]; od_ld8(bias + gn, bv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] += bv[e];
+            }
+            if (EPI == OD_EPI_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = od_silu(v[e]);
+            }
+            if (accumulate) {
+                float o[8]; od_ld8(dst, o);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] += o[e];
+            }
+            od_st8(dst, v);
+        } else {
+            for (int e = 0; e < 8 && gn + e < N; e++) {
+                float x = v[e] + (bias ? bias[gn + e] : 0.f);
+                if (EPI == OD_EPI_SILU) x = od_silu(x);
+                if (accumulate) x += od_t<T>::ld(dst + e);
+                od_t<T>::st(dst + e, x);
+            }
+        }
+    }
+}
+
+// ---- TN: dW[n][k] += sum_m G[m][n] * A[m][k] over this block's M range ----------
+template <class T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ A, int lda,
+                                                      float* __restrict__ dW, int lddw, int M, int N, int K, int m_per_block) {
+    constexpr int BR = 128 / (int)sizeof(T);  // reduction rows per slab (64 bf16 / 32 f32)
+    constexpr int CH = 16 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+    const int tiles_n = (N + BN - 1) / BN, tiles_k = (K + BM - 1) / BM;
+    const int tile = blockIdx.x % (tiles_n * tiles_k), split = blockIdx.x / (tiles_n * tiles_k);
+    const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BM;
+    const int mb = split * m_per_block;
+    int me = mb + m_per_block; me = me < M ? me : M;
+    if (mb >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4)(0.f);
+
+    // a slab is BR rows x 128 columns of each operand = BR*128/CH chunks = 2048 (bf16: 64*16) / 1024 (f32: 32*32)
+    constexpr int CPR = 128 / CH;              // chunks per row
+    constexpr int NCH = BR * CPR / 256;        // chunks per thread per operand
+    u32x4 rg[NCH], ra[NCH];
+    const int nslab = (me - mb + BR - 1) / BR;
+
+    auto gload = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = tid + 256 * i, r = c / CPR, cc = (c % CPR) * CH;
+            const int m = mb + st * BR + r;
+            const bool mv = m < me;
+            rg[i] = (mv && n0 + cc < N) ? *(const u32x4*)(G + (size_t)m * ldg + n0 + cc) : (u32x4)(0u);
+            ra[i] = (mv && k0 + cc < K) ? *(const u32x4*)(A + (size_t)m * lda + k0 + cc) : (u32x4)(0u);
+        }
+    };
+    // transposing store: element (r, col) of the slab -> LDS row `col`, reduction index r
+    auto lstore = [&](int buf) {
+        unsigned char* sA = smem + buf * STAGE_BYTES;   // G^T : rows = n
+        unsigned char* sB = sA + 16384;                  // A^T : rows = k
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = tid + 256 * i, r = c / CPR, cc = (c % CPR) * CH;
+            const T* pg = (const T*)&rg[i];
+            const T* pa = (const T*)&ra[i];
+            const int rb = r * (int)sizeof(T);
+#pragma unroll
+            for (int e = 0; e < CH; e++) {
+                const int row = cc + e;
+                const int off = row * 128 + ((((rb >> 4)) ^ (row & 7)) << 4) + (rb & 15);
+                *(T*)(sA + off) = pg[e];
+                *(T*)(sB + off) = pa[e];
+            }
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int st = 0; st < nslab; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nslab) gload(st + 1);
+        compute_stage<T>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+        if (st + 1 < nslab) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // NOTE rows of the G^T panel whose n >= N were never written with real data: they were
+    // loaded as zeros (predicate above), so the out-of-range accumulators are simply dropped.
+    const int col = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + wm * 64 + i * 16 + g * 4 + r, k = k0 + wn * 64 + j * 16 + col;
+                if (n < N && k < K) atomicAdd(dW + (size_t)n * lddw + k, acc[i][j][r]);
+            }
+}
+
+// column sums (bias gradients): out[n] += sum_m G[m][n]
+template <class T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ G, int ldg, float* __restrict__ out, int M, int N,
+                                                     int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int mb = blockIdx.y * rows_per_block;
+    int me = mb + rows_per_block; me = me < M ? me : M;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = mb; m < me; m++) s += od_t<T>::ld(G + (size_t)m * ldg + n);
+    atomicAdd(out + n, s);
+}
+
+template <class T>
+int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C, int ldc, int M, int N, int K, int epi,
+              int accumulate, hipStream_t st) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    if (epi == OD_EPI_SILU)
+        OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_SILU>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+    else
+        OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_NONE>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+template <class T>
+int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, int M, int N, int K, hipStream_t st) {
+    constexpr int BR = 128 / (int)sizeof(T);
+    const int tiles = ((N + BN - 1) / BN) * ((K + BM - 1) / BM);
+    int splits = (2048 + tiles - 1) / tiles;                 // aim for ~2048 workgroups (8 per CU)
+    int mpb = (M + splits - 1) / splits;
+    mpb = ((mpb + BR - 1) / BR) * BR;
+    if (mpb < 4 * BR) mpb = 4 * BR;
+    splits = (M + mpb - 1) / mpb;
+    OD_LAUNCH((gemm_tn_kernel<T>), dim3(tiles * splits), dim3(256), 0, st, G, ldg, A, lda, dW, lddw, M, N, K, mpb);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                          int M, int N, int K, int epilogue, int accumulate, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return OD_ERR_ARG;
+    const int ch = dtype == OD_BF16 ? 8 : 4;
+    if (lda % ch || ldw % ch || K % ch) return OD_ERR_ALIGN;
+    if (dtype == OD_BF16)
+        return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
+    if (dtype == OD_F32)
+        return launch_nt<float>((const float*)A, lda, (const float*)W, ldw, bias, (float*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
+    return OD_ERR_ARG;
+}
+
+extern "C" int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, int M, int N, int K,
+                          void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return OD_ERR_ARG;
+    const int ch = dtype == OD_BF16 ? 8 : 4;
+    if (ldg % ch || lda % ch) return OD_ERR_ALIGN;
+    if (dtype == OD_BF16) return launch_tn<bf16_t>((const bf16_t*)G, ldg, (const bf16_t*)A, lda, dW, lddw, M, N, K, (hipStream_t)stream);
+    if (dtype == OD_F32) return launch_tn<float>((const float*)G, ldg, (const float*)A, lda, dW, lddw, M, N, K, (hipStream_t)stream);
+    return OD_ERR_ARG;
+}
+
+extern "C" int od_colsum(int dtype, const void* G, int ldg, float* out, int M, int N, void* stream) {
+    if (M <= 0 || N <= 0) return OD_ERR_ARG;
+    int rpb = (M + 255) / 256; if (rpb < 64) rpb = 64;
+    dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+    if (dtype == OD_BF16) OD_LAUNCH((colsum_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)G, ldg, out, M, N, rpb);
+    else OD_LAUNCH((colsum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)G, ldg, out, M, N, rpb);
+    OD_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,414 @@
+// Boundary/layout kernels, depthwise Conv1d, per-sample linears, weight packing.
+#include "od_common.h"
+#include "od_api_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------ (B,C,L) f32 -> frame-major rows
+template <class T>
+__global__ __launch_bounds__(256) void cl_to_frames_kernel(const float* __restrict__ src, T* __restrict__ dst, int ldd, int C, int L) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, l0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {               // read: lanes along frames (contiguous)
+        const int c = c0 + i, l = l0 + tx;
+        tile[i][tx] = (c < C && l < L) ? src[((size_t)b * C + c) * L + l] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {               // write: lanes along channels (contiguous)
+        const int l = l0 + i, c = c0 + tx;
+        if (l < L && c < C) od_t<T>::st(dst + ((size_t)b * L + l) * ldd + c, tile[tx][i]);
+    }
+}
+
+// ------------------------------------------------------------ proj_in: E (<=8) channels -> D
+template <class T>
+__global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ xt, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, T* __restrict__ x, int ldx,
+                                                      int B, int E, int L, int D) {
+    const int lane = threadIdx.x & 63;
+    const long M = (long)B * L;
+    const long nw = (long)gridDim.x * 4, w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int c = lane * 8; c < D; c += 512) {
+        float wv[8][8], bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            bv[k] = bias[c + k];
+#pragma unroll
+            for (int e = 0; e < 8; e++) wv[k][e] = e < E ? W[(size_t)(c + k) * E + e] : 0.f;
+        }
+        for (long m = w0; m < M; m += nw) {
+            const int b = (int)(m / L), l = (int)(m % L);
+            float xe[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) xe[e] = e < E ? xt[((size_t)b * E + e) * L + l] : 0.f;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float s = bv[k];
+#pragma unroll
+                for (int e = 0; e < 8; e++) s += wv[k][e] * xe[e];
+                o[k] = s;
+            }
+            od_st8(x + m * ldx + c, o);
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void proj_in_bwd_kernel(const float* __restrict__ xt, const T* __restrict__ dx, int ldx,
+                                                          float* __restrict__ dW, float* __restrict__ db, int B, int E, int L, int D) {
+    const int lane = threadIdx.x & 63;
+    const long M = (long)B * L;
+    const long nw = (long)gridDim.x * 4, w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int c = lane * 8; c < D; c += 512) {
+        float aw[8][8], ab[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            ab[k] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) aw[k][e] = 0.f;
+        }
+        for (long m = w0; m < M; m += nw) {
+            const int b = (int)(m / L), l = (int)(m % L);
+            float xe[8], g[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) xe[e] = e < E ? xt[((size_t)b * E + e) * L + l] : 0.f;
+            od_ld8(dx + m * ldx + c, g);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                ab[k] += g[k];
+#pragma unroll
+                for (int e = 0; e < 8; e++) aw[k][e] += g[k] * xe[e];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            atomicAdd(db + c + k, ab[k]);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (e < E) atomicAdd(dW + (size_t)(c + k) * E + e, aw[k][e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------ elementwise SiLU
+template <class T>
+__global__ __launch_bounds__(256) void silu_kernel(const T* __restrict__ x, T* __restrict__ y, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8]; od_ld8(x + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = od_silu(v[e]);
+        od_st8(y + i * 8, v);
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8], g[8]; od_ld8(x + i * 8, v); od_ld8(dy + i * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; e++) g[e] *= od_silu_grad(v[e]);
+        od_st8(dx + i * 8, g);
+    }
+}
+
+// ------------------------------------------------------------ depthwise conv along frames
+// thread = 8 channels x a run of RUN frames, sliding a K-tap register window down the frames.
+constexpr int DW_RUN = 32;
+template <class T, int KS>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, T* __restrict__ y, int ldy,
+                                                     int L, int C) {
+    constexpr int R = KS / 2;
+    const int cg = C / 8;
+    const int b = blockIdx.y;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cgi = (int)(t % cg);
+    const long run = t / cg;
+    const int l0 = (int)(run * DW_RUN);
+    if (l0 >= L) return;
+    const int c = cgi * 8;
+    float wv[8][KS], bv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        bv[k] = bias[c + k];
+#pragma unroll
+        for (int j = 0; j < KS; j++) wv[k][j] = w[(size_t)(c + k) * KS + j];
+    }
+    float win[KS][8];
+    const T* xb = x + (size_t)b * L * ldx + c;
+#pragma unroll
+    for (int j = 0; j < KS - 1; j++) {
+        const int l = l0 - R + j;
+        if (l >= 0 && l < L) od_ld8(xb + (size_t)l * ldx, win[j]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) win[j][k] = 0.f;
+        }
+    }
+    for (int i = 0; i < DW_RUN; i++) {
+        const int l = l0 + i;
+        if (l >= L) break;
+        const int ln = l + R;
+        if (ln < L) od_ld8(xb + (size_t)ln * ldx, win[KS - 1]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) win[KS - 1][k] = 0.f;
+        }
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float s = bv[k];
+#pragma unroll
+            for (int j = 0; j < KS; j++) s += wv[k][j] * win[j][k];
+            o[k] = s;
+        }
+        od_st8(y + ((size_t)b * L + l) * ldy + c, o);
+#pragma unroll
+        for (int j = 0; j < KS - 1; j++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) win[j][k] = win[j + 1][k];
+    }
+}
+
+// backward: dx[l] = sum_j w[j] dy[l - j + R];  dw[j] += sum_l dy[l] x[l + j - R];  db += sum_l dy[l]
+template <class T, int KS>
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                         const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx,
+                                                         float* __restrict__ dw, float* __restrict__ db, int L, int C) {
+    constexpr int R = KS / 2;
+    const int cg = C / 8;
+    const int b = blockIdx.y;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cgi = (int)(t % cg);
+    const long run = t / cg;
+    const int l0 = (int)(run * DW_RUN);
+    if (l0 >= L) return;
+    const int c = cgi * 8;
+    float wv[8][KS], adw[8][KS], adb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        adb[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; j++) { wv[k][j] = w[(size_t)(c + k) * KS + j]; adw[k][j] = 0.f; }
+    }
+    // windows over frames l-R .. l+R of both dy (for dx) and x (for dw)
+    float wy[KS][8], wx[KS][8];
+    const T* xb = x + (size_t)b * L * ldx + c;
+    const T* yb = dy + (size_t)b * L * lddy + c;
+#pragma unroll
+    for (int j = 0; j < KS - 1; j++) {
+        const int l = l0 - R + j;
+        if (l >= 0 && l < L) { od_ld8(xb + (size_t)l * ldx, wx[j]); od_ld8(yb + (size_t)l * lddy, wy[j]); }
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { wx[j][k] = 0.f; wy[j][k] = 0.f; }
+        }
+    }
+    for (int i = 0; i < DW_RUN; i++) {
+        const int l = l0 + i;
+        if (l >= L) break;
+        const int ln = l + R;
+        if (ln < L) { od_ld8(xb + (size_t)ln * ldx, wx[KS - 1]); od_ld8(yb + (size_t)ln * lddy, wy[KS - 1]); }
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { wx[KS - 1][k] = 0.f; wy[KS - 1][k] = 0.f; }
+        }
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float s = 0.f;
+            // window slot j holds frame l - R + j; dx[l] += w[jj] * dy[l - jj + R]  ->  slot = 2R - jj
+#pragma unroll
+            for (int jj = 0; jj < KS; jj++) s += wv[k][jj] * wy[KS - 1 - jj][k];
+            o[k] = s;
+            const float g = wy[R][k];     // dy[l]
+            adb[k] += g;
+#pragma unroll
+            for (int jj = 0; jj < KS; jj++) adw[k][jj] += g * wx[jj][k];   // x[l + jj - R]
+        }
+        od_st8(dx + ((size_t)b * L + l) * lddx + c, o);
+#pragma unroll
+        for (int j = 0; j < KS - 1; j++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) { wx[j][k] = wx[j + 1][k]; wy[j][k] = wy[j + 1][k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        atomicAdd(db + c + k, adb[k]);
+#pragma unroll
+        for (int j = 0; j < KS; j++) atomicAdd(dw + (size_t)(c + k) * KS + j, adw[k][j]);
+    }
+}
+
+// ------------------------------------------------------------ per-sample linear: one wave per output feature
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           float* __restrict__ pre, int B, int N, int K, int act) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    for (int b = 0; b < B; b++) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += x[(size_t)b * K + k] * W[(size_t)n * K + k];
+        s = od_wave_sum(s);
+        if (lane == 0) {
+            s += bias ? bias[n] : 0.f;
+            if (pre) pre[(size_t)b * N + n] = s;
+            out[(size_t)b * N + n] = act == OD_ACT_SILU ? od_silu(s) : s;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void linear_small_dpre_kernel(const float* __restrict__ pre, const float* __restrict__ dout,
+                                                                float* __restrict__ dpre, long n, int act) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    dpre[i] = act == OD_ACT_SILU ? dout[i] * od_silu_grad(pre[i]) : dout[i];
+}
+// dW[n][k] += sum_b dpre[b][n] x[b][k]; db[n] += sum_b dpre[b][n]     (wave per n, lanes over k)
+__global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
+                                                              float* __restrict__ dW, float* __restrict__ db, int B, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    if (dW)
+        for (int k = lane; k < K; k += 64) {
+            float s = 0.f;
+            for (int b = 0; b < B; b++) s += dpre[(size_t)b * N + n] * x[(size_t)b * K + k];
+            dW[(size_t)n * K + k] += s;
+        }
+    if (db && lane == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; b++) s += dpre[(size_t)b * N + n];
+        db[n] += s;
+    }
+}
+// dx[b][k] (+)= sum_n dpre[b][n] W[n][k]
+__global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __restrict__ W, const float* __restrict__ dpre,
+                                                              float* __restrict__ dx, int accumulate, int B, int N, int K) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int n = 0; n < N; n++) s += dpre[(size_t)b * N + n] * W[(size_t)n * K + k];
+    if (accumulate) dx[(size_t)b * K + k] += s; else dx[(size_t)b * K + k] = s;
+}
+
+// ------------------------------------------------------------ fp32 master weight -> packed compute copy
+template <class T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, int N, int K, T* __restrict__ dst,
+                                                          int Np, int Kp, int transpose, const int* __restrict__ row_map) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Np * Kp) return;
+    int n, k;
+    if (!transpose) { n = (int)(i / Kp); k = (int)(i % Kp); }     // dst[n][k]
+    else { k = (int)(i / Np); n = (int)(i % Np); }                // dst[k][n]
+    const int sn = row_map ? row_map[n] : (n < N ? n : -1);
+    const float v = (sn >= 0 && k < K) ? src[(size_t)sn * K + k] : 0.f;
+    od_t<T>::st(dst + i, v);
+}
+
+}  // namespace
+
+#define DISPATCH_T(DT, CALL)                                       \
+    do {                                                           \
+        if ((DT) == OD_BF16) { typedef bf16_t T_; CALL; }          \
+        else if ((DT) == OD_F32) { typedef float T_; CALL; }       \
+        else return OD_ERR_ARG;                                    \
+    } while (0)
+
+extern "C" int od_cl_to_frames(int dtype, const float* src, void* dst, int ldd, int B, int C, int L, void* stream) {
+    dim3 grid((L + 63) / 64, (C + 63) / 64, B);
+    DISPATCH_T(dtype, OD_LAUNCH((cl_to_frames_kernel<T_>), grid, dim3(256), 0, (hipStream_t)stream, src, (T_*)dst, ldd, C, L));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_proj_in(int dtype, const float* xt, const float* W, const float* bias, void* x, int ldx, int B, int E, int L,
+                          int D, void* stream) {
+    if (E > 8) return OD_ERR_UNSUPPORTED;
+    if (D % 8 || ldx % 8) return OD_ERR_ALIGN;
+    const long M = (long)B * L;
+    int blocks = (int)((M + 3) / 4); if (blocks > 4096) blocks = 4096;
+    DISPATCH_T(dtype, OD_LAUNCH((proj_in_kernel<T_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, xt, W, bias, (T_*)x, ldx, B, E, L, D));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_proj_in_bwd(int dtype, const float* xt, const void* dx, int ldx, float* dW, float* db, int B, int E, int L, int D,
+                              void* stream) {
+    if (E > 8) return OD_ERR_UNSUPPORTED;
+    if (D % 8 || ldx % 8) return OD_ERR_ALIGN;
+    const long M = (long)B * L;
+    int blocks = (int)((M + 63) / 64); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    DISPATCH_T(dtype, OD_LAUNCH((proj_in_bwd_kernel<T_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, xt, (const T_*)dx, ldx, dW, db, B, E, L, D));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_silu(int dtype, const void* x, void* y, long n, void* stream) {
+    if (n % 8) return OD_ERR_ALIGN;
+    long n8 = n / 8; int blocks = (int)((n8 + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    DISPATCH_T(dtype, OD_LAUNCH((silu_kernel<T_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T_*)x, (T_*)y, n8));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int od_silu_bwd(int dtype, const void* x, const void* dy, void* dx, long n, void* stream) {
+    if (n % 8) return OD_ERR_ALIGN;
+    long n8 = n / 8; int blocks = (int)((n8 + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    DISPATCH_T(dtype, OD_LAUNCH((silu_bwd_kernel<T_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T_*)x, (const T_*)dy, (T_*)dx, n8));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_dwconv(int dtype, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int L,
+                         int C, int ksize, void* stream) {
+    if (C % 8 || ldx % 8 || ldy % 8) return OD_ERR_ALIGN;
+    const long threads = (long)(C / 8) * ((L + DW_RUN - 1) / DW_RUN);
+    dim3 grid((unsigned)((threads + 255) / 256), B);
+    if (ksize == 5) DISPATCH_T(dtype, OD_LAUNCH((dwconv_kernel<T_, 5>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, bias, (T_*)y, ldy, L, C));
+    else if (ksize == 3) DISPATCH_T(dtype, OD_LAUNCH((dwconv_kernel<T_, 3>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, bias, (T_*)y, ldy, L, C));
+    else return OD_ERR_UNSUPPORTED;
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_dwconv_bwd(int dtype, const void* x, int ldx, const float* w, const void* dy, int lddy, void* dx, int lddx,
+                             float* dw, float* db, int B, int L, int C, int ksize, void* stream) {
+    if (C % 8 || ldx % 8 || lddy % 8 || lddx % 8) return OD_ERR_ALIGN;
+    const long threads = (long)(C / 8) * ((L + DW_RUN - 1) / DW_RUN);
+    dim3 grid((unsigned)((threads + 255) / 256), B);
+    if (ksize == 5) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 5>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
+    else if (ksize == 3) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 3>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
+    else return OD_ERR_UNSUPPORTED;
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_linear_small(const float* x, const float* W, const float* b, float* out, float* pre, int B, int N, int K, int act,
+                               void* stream) {
+    OD_LAUNCH(linear_small_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, out, pre, B, N, K, act);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_linear_small_bwd(const float* x, const float* W, const float* pre, const float* dout, float* dpre, float* dW,
+                                   float* db, float* dx, int accumulate_dx, int B, int N, int K, int act, void* stream) {
+    if (act != OD_ACT_NONE && !pre) return OD_ERR_ARG;
+    const long n = (long)B * N;
+    OD_LAUNCH(linear_small_dpre_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, dout, dpre, n, act);
+    if (dW || db)
+        OD_LAUNCH(linear_small_dw_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (const float*)dpre, dW, db, B, N, K);
+    if (dx)
+        OD_LAUNCH(linear_small_dx_kernel, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, W, (const float*)dpre, dx, accumulate_dx, B, N, K);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_pack_weight(int dtype, const float* src, int N, int K, void* dst, int Np, int Kp, int transpose,
+                              const int* row_map, void* stream) {
+    const long n = (long)Np * Kp;
+    DISPATCH_T(dtype, OD_LAUNCH((pack_weight_kernel<T_>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, K, (T_*)dst, Np, Kp, transpose, row_map));
+    OD_CHECK_LAUNCH();
+    return 0;
+}

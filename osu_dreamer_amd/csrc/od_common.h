@@ -1,0 +1,138 @@
+// Shared device helpers for the osu-dreamer denoiser kernels (gfx950 / CDNA4).
+//
+// Internal activation layout is FRAME-MAJOR: a (batch, channel, frame) tensor of the
+// reference is held as rows = frames (m = b*L + l), columns = channels, channel
+// contiguous.  Per-frame channel reductions (RMS norm) are then contiguous, every
+// 1x1 Conv1d is one NT GEMM over M = B*L rows, and attention heads are 64 contiguous
+// features per frame.  Only the boundary tensors (xt, audio, v) stay channel-major.
+#pragma once
+#if defined(OD_EMU)
+#include "emu_hip.h"
+#else
+#include <hip/hip_runtime.h>
+#define OD_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+// kernels whose dynamic LDS may exceed the 64 KiB default (gfx950 has 160 KiB per CU)
+#define OD_LAUNCH_DYN(kern, grid, block, smem, stream, ...)                                                    \
+    do {                                                                                                       \
+        static bool attr_set__ = false;                                                                        \
+        if (!attr_set__) {                                                                                     \
+            (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set__ = true;                                                                                 \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);                              \
+    } while (0)
+#define OD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define OD_WAVE 64
+
+__device__ __forceinline__ float od_bf2f(bf16_t h) {
+    union { uint32_t u; float f; } c; c.u = ((uint32_t)h) << 16; return c.f;
+}
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t od_f2bf(float f) {
+    union { uint32_t u; float f; } c; c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <class T> struct od_t;
+template <> struct od_t<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct od_t<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return od_bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = od_f2bf(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (p must be 16-byte aligned for bf16, 32 for f32)
+__device__ __forceinline__ void od_ld8(const float* p, float (&v)[8]) {
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void od_ld8(const bf16_t* p, float (&v)[8]) {
+    u32x4 r = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        union { uint32_t u; float f; } lo, hi;
+        lo.u = r[i] << 16; hi.u = r[i] & 0xffff0000u;
+        v[2 * i] = lo.f; v[2 * i + 1] = hi.f;
+    }
+}
+__device__ __forceinline__ void od_st8(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+    a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+    b[0] = v[4]; b[1] = v[5]; b[2] = v[6]; b[3] = v[7];
+    *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
+}
+__device__ __forceinline__ void od_st8(bf16_t* p, const float (&v)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = (uint32_t)od_f2bf(v[2 * i]) | ((uint32_t)od_f2bf(v[2 * i + 1]) << 16);
+    *(u32x4*)p = r;
+}
+
+__device__ __forceinline__ float od_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float od_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float od_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// d/dx [x*sigmoid(x)]
+__device__ __forceinline__ float od_silu_grad(float x) {
+    float s = od_sigmoid(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// ---------------------------------------------------------------------------------
+// MFMA fragment abstraction, one shape for both compute types: a 16x16 output tile
+// and a 32-deep K slab.  Each lane holds 8 K-consecutive elements of its row:
+//   A frag: row (lane&15), k = 8*(lane>>4) + j      B frag: col (lane&15), same k
+// bf16: one v_mfma_f32_16x16x32_bf16.  f32: eight v_mfma_f32_16x16x4_f32, the j-th
+// taking element j of every lane group — a K permutation applied identically to A
+// and B, hence the same dot product (exact f32 FMA chain).
+// Accumulator (both): col = lane&15, row = 4*(lane>>4) + r.
+// ---------------------------------------------------------------------------------
+template <class T> struct od_frag;
+template <> struct od_frag<bf16_t> { s16x8 v; };
+template <> struct od_frag<float> { float v[8]; };
+
+__device__ __forceinline__ void od_frag_load(od_frag<bf16_t>& f, const bf16_t* p) { f.v = *(const s16x8*)p; }
+__device__ __forceinline__ void od_frag_load(od_frag<float>& f, const float* p) { od_ld8(p, f.v); }
+__device__ __forceinline__ void od_frag_zero(od_frag<bf16_t>& f) { f.v = (s16x8)(0); }
+__device__ __forceinline__ void od_frag_zero(od_frag<float>& f) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) f.v[j] = 0.f;
+}
+__device__ __forceinline__ void od_frag_set(od_frag<bf16_t>& f, int j, float x) { f.v[j] = (short)od_f2bf(x); }
+__device__ __forceinline__ void od_frag_set(od_frag<float>& f, int j, float x) { f.v[j] = x; }
+
+__device__ __forceinline__ f32x4 od_mma(const od_frag<bf16_t>& a, const od_frag<bf16_t>& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 od_mma(const od_frag<float>& a, const od_frag<float>& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+    return c;
+}
+
+#define OD_CHECK_LAUNCH()                                \
+    do {                                                 \
+        hipError_t e__ = hipGetLastError();              \
+        if (e__ != hipSuccess) return -(int)e__ - 1000;  \
+    } while (0)

@@ -1,0 +1,120 @@
+// Fused optimizer pass over the flat parameter arena, plus hipGraph helpers and misc ABI.
+//   grad-norm clip (Lightning gradient_clip_val, models/diffusion/model.yml:39)
+//   -> AdamW (models/diffusion/train.py:110-118, torch defaults)
+//   -> EMA  (train.py:67,125-126: first update copies, then lerp by 1-decay)
+// One read of g/p/m/v/ema and one write of p/m/v/ema per element: 36 B/param, HBM-bound.
+#include "od_common.h"
+#include "od_api_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(g + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    s = od_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ ema, long n, float lr,
+                                                        float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                        float ema_decay, int ema_mode, const float* __restrict__ gnorm_sq,
+                                                        float max_norm) {
+    float clip = 1.f;
+    if (max_norm > 0.f && gnorm_sq) {
+        const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);
+        clip = c < 1.f ? c : 1.f;
+    }
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * clip;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (ema_mode == 1) ema[i] = pi;
+        else if (ema_mode == 2) { const float e = ema[i]; ema[i] = e + (1.f - ema_decay) * (pi - e); }
+    }
+}
+
+}  // namespace
+
+extern "C" int od_sqnorm(const float* g, long n, float* out, void* stream) {
+    int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    OD_LAUNCH(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, float ema_decay, int ema_mode, const float* gnorm_sq,
+                            float max_norm, void* stream) {
+    if (step < 1 || n <= 0) return OD_ERR_ARG;
+    if (ema_mode != 0 && !ema) return OD_ERR_ARG;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+    OD_LAUNCH(adamw_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, lr, beta1, beta2, eps,
+              weight_decay, bc1, bc2_sqrt, ema_decay, ema_mode, gnorm_sq, max_norm);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_version(void) { return 100; }
+
+extern "C" const char* od_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case OD_ERR_ARG: return "invalid argument";
+        case OD_ERR_ALIGN: return "leading dimension / size not aligned to the kernel's vector width";
+        case OD_ERR_UNSUPPORTED: return "shape outside the compiled kernel set";
+        default: break;
+    }
+#if !defined(OD_EMU)
+    if (code <= -1000) return hipGetErrorString((hipError_t)(-(code + 1000)));
+#endif
+    return "unknown error";
+}
+
+// ---- hipGraph capture of a launch sequence (the sampler loop) ---------------------------
+#if !defined(OD_EMU)
+extern "C" int od_graph_begin(void* stream) {
+    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+    return e == hipSuccess ? 0 : -(int)e - 1000;
+}
+extern "C" int od_graph_end(void* stream, void** graph_exec_out) {
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+    if (e != hipSuccess) return -(int)e - 1000;
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return -(int)e - 1000;
+    *graph_exec_out = (void*)exec;
+    return 0;
+}
+extern "C" int od_graph_launch(void* graph_exec, void* stream) {
+    hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : -(int)e - 1000;
+}
+extern "C" int od_graph_destroy(void* graph_exec) {
+    hipError_t e = hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+    return e == hipSuccess ? 0 : -(int)e - 1000;
+}
+#else
+extern "C" int od_graph_begin(void*) { return OD_ERR_UNSUPPORTED; }
+extern "C" int od_graph_end(void*, void**) { return OD_ERR_UNSUPPORTED; }
+extern "C" int od_graph_launch(void*, void*) { return OD_ERR_UNSUPPORTED; }
+extern "C" int od_graph_destroy(void*) { return OD_ERR_UNSUPPORTED; }
+#endif

@@ -1,0 +1,694 @@
+// Per-frame (row) kernels: channel RMS norm + adaLN modulation, gate/residual, SwiGLU
+// gate + RMS norm, final norm + proj_out, q/k RMSNorm + RoPE — forward and backward.
+// One wavefront owns a frame: channels are contiguous in the frame-major layout, so a
+// lane reads 8 consecutive channels (16 B bf16 / 32 B f32) and the per-frame reduction is
+// one 64-lane shuffle tree.  HBM-bound; algorithmic bytes are listed in DESIGN.md.
+#include "od_common.h"
+#include "od_api_internal.h"
+
+namespace {
+
+constexpr int ROWS_PER_WAVE_BWD = 16;  // rows a wave walks in kernels that also reduce over frames
+
+// load a row chunk-wise into registers: lane owns chunks lane, lane+64, ... of 8 channels
+template <class T, int NCH>
+__device__ __forceinline__ void load_row(const T* row, int C, int lane, float (&v)[NCH][8]) {
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < C) od_ld8(row + c, v[i]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[i][e] = 0.f;
+        }
+    }
+}
+template <int NCH>
+__device__ __forceinline__ float row_sumsq(const float (&v)[NCH][8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) s += v[i][e] * v[i][e];
+    return od_wave_sum(s);
+}
+
+// ------------------------------------------------------------------ rmsnorm + FiLM (+cl)
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_film_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ ssg,
+                                                           const T* __restrict__ cl, int ldcl, int cl_bcast,
+                                                           T* __restrict__ h, int ldh, float* __restrict__ inv_rms,
+                                                           int B, int L, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)B * L) return;
+    const int b = (int)(m / L), l = (int)(m % L);
+    float v[NCH][8];
+    load_row<T, NCH>(x + m * ldx, C, lane, v);
+    const float inv = rsqrtf(row_sumsq<NCH>(v) / (float)C + eps);
+    if (lane == 0 && inv_rms) inv_rms[m] = inv;
+    const float* sc = ssg + (size_t)b * 3 * C;
+    const T* clrow = cl ? cl + (size_t)(cl_bcast ? l : m) * ldcl : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+        if (c >= C) continue;
+        float s[8], sh[8], o[8];
+        od_ld8(sc + c, s); od_ld8(sc + C + c, sh);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = v[i][e] * inv * (1.f + s[e]) + sh[e];
+        if (clrow) {
+            float a[8]; od_ld8(clrow + c, a);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] += a[e];
+        }
+        od_st8(h + m * ldh + c, o);
+    }
+}
+
+// backward: dres += inv*(g - xhat*mean(g*xhat)), g = dh*(1+scale); dscale += dh*xhat; dshift += dh
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_film_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ inv_rms,
+                                                               const float* __restrict__ ssg, const T* __restrict__ dh, int lddh,
+                                                               T* __restrict__ dres, int lddres, float* __restrict__ dssg,
+                                                               int B, int L, int C) {
+    __shared__ float red[2][NCH * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * 4 + wave) * ROWS_PER_WAVE_BWD;
+    float dsc[NCH][8], dsh[NCH][8], scl[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { dsc[i][e] = 0.f; dsh[i][e] = 0.f; scl[i][e] = 0.f; }
+        if (c < C) od_ld8(ssg + (size_t)b * 3 * C + c, scl[i]);
+    }
+    for (int r = 0; r < ROWS_PER_WAVE_BWD; r++) {
+        const int l = l0 + r;
+        if (l >= L) break;
+        const long m = (long)b * L + l;
+        float xv[NCH][8], gv[NCH][8];
+        load_row<T, NCH>(x + m * ldx, C, lane, xv);
+        load_row<T, NCH>(dh + m * lddh, C, lane, gv);
+        const float inv = inv_rms[m];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float xh = xv[i][e] * inv;
+                dsc[i][e] += gv[i][e] * xh;
+                dsh[i][e] += gv[i][e];
+                gv[i][e] *= (1.f + scl[i][e]);
+                dot += gv[i][e] * xh;
+                xv[i][e] = xh;
+            }
+        dot = od_wave_sum(dot) / (float)C;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = (lane + 64 * i) * 8;
+            if (c >= C) continue;
+            float o[8];
+            od_ld8(dres + m * lddres + c, o);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] += inv * (gv[i][e] - xv[i][e] * dot);
+            od_st8(dres + m * lddres + c, o);
+        }
+    }
+    // cross-wave reduction of the per-(b,c) sums, then one atomic per channel per block
+    for (int w = 0; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NCH; i++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int idx = (lane + 64 * i) * 8 + e;
+                    if (w == 0) { red[0][idx] = dsc[i][e]; red[1][idx] = dsh[i][e]; }
+                    else { red[0][idx] += dsc[i][e]; red[1][idx] += dsh[i][e]; }
+                }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dssg + (size_t)b * 3 * C + c, red[0][c]);
+        atomicAdd(dssg + (size_t)b * 3 * C + C + c, red[1][c]);
+    }
+}
+
+// ------------------------------------------------------------------ rmsnorm * gate + residual
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_gate_res_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ h, int ldh,
+                                                               const float* __restrict__ ssg, T* __restrict__ xo, int ldxo,
+                                                               float* __restrict__ inv_rms, int B, int L, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)B * L) return;
+    const int b = (int)(m / L);
+    float v[NCH][8];
+    load_row<T, NCH>(h + m * ldh, C, lane, v);
+    const float inv = rsqrtf(row_sumsq<NCH>(v) / (float)C + eps);
+    if (lane == 0 && inv_rms) inv_rms[m] = inv;
+    const float* gate = ssg + (size_t)b * 3 * C + 2 * C;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+        if (c >= C) continue;
+        float g[8], o[8];
+        od_ld8(gate + c, g);
+        od_ld8(x + m * ldx + c, o);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] += v[i][e] * inv * g[e];
+        od_st8(xo + m * ldxo + c, o);
+    }
+}
+
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_gate_res_bwd_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ inv_rms,
+                                                                   const float* __restrict__ ssg, const T* __restrict__ dy, int lddy,
+                                                                   T* __restrict__ dh, int lddh, float* __restrict__ dssg,
+                                                                   int B, int L, int C) {
+    __shared__ float red[NCH * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * 4 + wave) * ROWS_PER_WAVE_BWD;
+    float dg[NCH][8], gate[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { dg[i][e] = 0.f; gate[i][e] = 0.f; }
+        if (c < C) od_ld8(ssg + (size_t)b * 3 * C + 2 * C + c, gate[i]);
+    }
+    for (int r = 0; r < ROWS_PER_WAVE_BWD; r++) {
+        const int l = l0 + r;
+        if (l >= L) break;
+        const long m = (long)b * L + l;
+        float hv[NCH][8], gv[NCH][8];
+        load_row<T, NCH>(h + m * ldh, C, lane, hv);
+        load_row<T, NCH>(dy + m * lddy, C, lane, gv);
+        const float inv = inv_rms[m];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float hh = hv[i][e] * inv;
+                dg[i][e] += gv[i][e] * hh;
+                gv[i][e] *= gate[i][e];
+                dot += gv[i][e] * hh;
+                hv[i][e] = hh;
+            }
+        dot = od_wave_sum(dot) / (float)C;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = (lane + 64 * i) * 8;
+            if (c >= C) continue;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = inv * (gv[i][e] - hv[i][e] * dot);
+            od_st8(dh + m * lddh + c, o);
+        }
+    }
+    for (int w = 0; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < NCH; i++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int idx = (lane + 64 * i) * 8 + e;
+                    if (w == 0) red[idx] = dg[i][e]; else red[idx] += dg[i][e];
+                }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dssg + (size_t)b * 3 * C + 2 * C + c, red[c]);
+}
+
+// ------------------------------------------------------------------ SwiGLU gate + RMS norm over Hf
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void swiglu_rmsnorm_kernel(const T* __restrict__ vg, int ldvg, T* __restrict__ hh, int ldhh,
+                                                             float* __restrict__ inv_rms, long M, int Hf, int Hp, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float v[NCH][8], g[NCH][8];
+    load_row<T, NCH>(vg + m * ldvg, Hp, lane, v);
+    load_row<T, NCH>(vg + m * ldvg + Hp, Hp, lane, g);
+#pragma unroll
+    for (int i = 0; i < NCH; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[i][e] *= od_silu(g[i][e]);
+    const float inv = rsqrtf(row_sumsq<NCH>(v) / (float)Hf + eps);
+    if (lane == 0 && inv_rms) inv_rms[m] = inv;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+        if (c >= Hp) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = v[i][e] * inv;
+        od_st8(hh + m * ldhh + c, o);
+    }
+}
+
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void swiglu_rmsnorm_bwd_kernel(const T* __restrict__ vg, int ldvg, const float* __restrict__ inv_rms,
+                                                                 const T* __restrict__ dhh, int lddhh, T* __restrict__ dvg, int lddvg,
+                                                                 long M, int Hf, int Hp) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float v[NCH][8], g[NCH][8], d[NCH][8];
+    load_row<T, NCH>(vg + m * ldvg, Hp, lane, v);
+    load_row<T, NCH>(vg + m * ldvg + Hp, Hp, lane, g);
+    load_row<T, NCH>(dhh + m * lddhh, Hp, lane, d);
+    const float inv = inv_rms[m];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) dot += d[i][e] * (v[i][e] * od_silu(g[i][e]) * inv);
+    dot = od_wave_sum(dot) / (float)Hf;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+        if (c >= Hp) continue;
+        float ov[8], og[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float sg = od_silu(g[i][e]);
+            const float sh = v[i][e] * sg * inv;
+            const float ds = inv * (d[i][e] - sh * dot);
+            ov[e] = ds * sg;
+            og[e] = ds * v[i][e] * od_silu_grad(g[i][e]);
+        }
+        od_st8(dvg + m * lddvg + c, ov);
+        od_st8(dvg + m * lddvg + Hp + c, og);
+    }
+}
+
+// ------------------------------------------------------------------ final rms_norm + proj_out (C -> E<=8)
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void final_proj_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ vout,
+                                                         float* __restrict__ inv_rms, int B, int L, int C, int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)B * L) return;
+    const int b = (int)(m / L), l = (int)(m % L);
+    float v[NCH][8];
+    load_row<T, NCH>(x + m * ldx, C, lane, v);
+    const float inv = rsqrtf(row_sumsq<NCH>(v) / (float)C + eps);
+    if (lane == 0 && inv_rms) inv_rms[m] = inv;
+    for (int e = 0; e < E; e++) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = (lane + 64 * i) * 8;
+            if (c >= C) continue;
+            float w[8]; od_ld8(W + (size_t)e * C + c, w);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += w[k] * v[i][k];
+        }
+        s = od_wave_sum(s) * inv;
+        if (lane == 0) vout[((size_t)b * E + e) * L + l] = s + bias[e];
+    }
+}
+
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void final_proj_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ inv_rms,
+                                                             const float* __restrict__ W, const float* __restrict__ dv,
+                                                             T* __restrict__ dx, int lddx, float* __restrict__ dW,
+                                                             float* __restrict__ db, int B, int L, int C, int E) {
+    constexpr int MAXE = 8;
+    __shared__ float red[MAXE * NCH * 512];
+    __shared__ float redb[4][MAXE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * 4 + wave) * ROWS_PER_WAVE_BWD;
+    float wv[MAXE][NCH][8], dw[MAXE][NCH][8], dbv[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) {
+        dbv[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = (lane + 64 * i) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { wv[e][i][k] = 0.f; dw[e][i][k] = 0.f; }
+            if (e < E && c < C) od_ld8(W + (size_t)e * C + c, wv[e][i]);
+        }
+    }
+    for (int r = 0; r < ROWS_PER_WAVE_BWD; r++) {
+        const int l = l0 + r;
+        if (l >= L) break;
+        const long m = (long)b * L + l;
+        float xv[NCH][8], dn[NCH][8], dve[MAXE];
+        load_row<T, NCH>(x + m * ldx, C, lane, xv);
+        const float inv = inv_rms[m];
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) { dve[e] = e < E ? dv[((size_t)b * E + e) * L + l] : 0.f; dbv[e] += dve[e]; }
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; i++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float xh = xv[i][k] * inv;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < MAXE; e++) { s += dve[e] * wv[e][i][k]; dw[e][i][k] += dve[e] * xh; }
+                dn[i][k] = s;
+                dot += s * xh;
+                xv[i][k] = xh;
+            }
+        dot = od_wave_sum(dot) / (float)C;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int c = (lane + 64 * i) * 8;
+            if (c >= C) continue;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[k] = inv * (dn[i][k] - xv[i][k] * dot);
+            od_st8(dx + m * lddx + c, o);
+        }
+    }
+    if (lane == 0)
+        for (int e = 0; e < MAXE; e++) redb[wave][e] = dbv[e];
+    for (int w = 0; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int e = 0; e < MAXE; e++)
+#pragma unroll
+                for (int i = 0; i < NCH; i++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int idx = e * NCH * 512 + (lane + 64 * i) * 8 + k;
+                        if (w == 0) red[idx] = dw[e][i][k]; else red[idx] += dw[e][i][k];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = 0; e < E; e++)
+        for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dW + (size_t)e * C + c, red[e * NCH * 512 + c]);
+    if (threadIdx.x < E) atomicAdd(db + threadIdx.x, redb[0][threadIdx.x] + redb[1][threadIdx.x] + redb[2][threadIdx.x] + redb[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ q/k RMSNorm(hd) + RoPE
+// lane owns 8 consecutive features of one head; a head spans hd/8 adjacent lanes.
+template <class T>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
+                                                           const float* __restrict__ wk, const float* __restrict__ table,
+                                                           T* __restrict__ out, int ldo, int B, int L, int H, int hd, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)B * L) return;
+    const int l = (int)(m % L);
+    const int lph = hd / 8, half = lph / 2;
+    const int nchunks = 2 * H * lph;
+    const int niter = (nchunks + 63) / 64;
+    for (int it = 0; it < niter; it++) {
+        const int q = it * 64 + lane;
+        const bool act = q < nchunks;
+        const int slot = q / lph, c8 = q % lph;
+        float v[8];
+        if (act) od_ld8(qkv + m * ldqkv + (size_t)slot * hd + c8 * 8, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = 0.f;
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) ss += v[e] * v[e];
+        for (int msk = 1; msk < lph; msk <<= 1) ss += __shfl_xor(ss, msk);
+        const float inv = rsqrtf(ss / (float)hd + eps);
+        const float* w = (slot < H ? wq : wk) + c8 * 8;
+        float y[8], p[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) y[e] = act ? v[e] * inv * w[e] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) p[e] = __shfl_xor(y[e], half);
+        if (act) {
+            const bool first = c8 < half;
+            const int j0 = (c8 % half) * 8;
+            const float* tb = table + ((size_t)l * (hd / 2) + j0) * 2;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float cs = tb[2 * e], sn = tb[2 * e + 1];
+                o[e] = first ? (y[e] * cs - p[e] * sn) : (p[e] * sn + y[e] * cs);
+            }
+            od_st8(out + m * ldo + (size_t)slot * hd + c8 * 8, o);
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
+                                                               const float* __restrict__ wk, const float* __restrict__ table,
+                                                               const T* __restrict__ dqk, int lddqk, T* __restrict__ dqkv, int lddqkv,
+                                                               float* __restrict__ dwq, float* __restrict__ dwk,
+                                                               int B, int L, int H, int hd, float eps) {
+    __shared__ float sdw[2][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 512; i += 256) sdw[i >> 8][i & 255] = 0.f;
+    __syncthreads();
+    const int lph = hd / 8, half = lph / 2;
+    const int nchunks = 2 * H * lph;
+    const int niter = (nchunks + 63) / 64;
+    float aq[8], ak[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { aq[e] = 0.f; ak[e] = 0.f; }
+    const long M = (long)B * L;
+    const long mbase = ((long)blockIdx.x * 4 + wave) * ROWS_PER_WAVE_BWD;
+    for (int r = 0; r < ROWS_PER_WAVE_BWD; r++) {
+        const long m = mbase + r;
+        if (m >= M) break;
+        const int l = (int)(m % L);
+        for (int it = 0; it < niter; it++) {
+            const int q = it * 64 + lane;
+            const bool act = q < nchunks;
+            const int slot = q / lph, c8 = q % lph;
+            float v[8], d[8];
+            if (act) { od_ld8(qkv + m * ldqkv + (size_t)slot * hd + c8 * 8, v); od_ld8(dqk + m * lddqk + (size_t)slot * hd + c8 * 8, d); }
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) { v[e] = 0.f; d[e] = 0.f; }
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) ss += v[e] * v[e];
+            for (int msk = 1; msk < lph; msk <<= 1) ss += __shfl_xor(ss, msk);
+            const float inv = rsqrtf(ss / (float)hd + eps);
+            // un-rotate the gradient: dy1 = d1*c + d2*s ; dy2 = -d1*s + d2*c
+            float p[8], dy[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) p[e] = __shfl_xor(d[e], half);
+            const bool first = c8 < half;
+            const int j0 = (c8 % (half > 0 ? half : 1)) * 8;
+            const float* tb = table + ((size_t)l * (hd / 2) + j0) * 2;
+            const float* w = (slot < H ? wq : wk) + c8 * 8;
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float cs = act ? tb[2 * e] : 0.f, sn = act ? tb[2 * e + 1] : 0.f;
+                dy[e] = first ? (d[e] * cs + p[e] * sn) : (-p[e] * sn + d[e] * cs);
+                const float xh = v[e] * inv;
+                const float wv = act ? w[e] : 0.f;
+                if (act) { if (slot < H) aq[e] += dy[e] * xh; else ak[e] += dy[e] * xh; }
+                dy[e] *= wv;              // d xhat
+                dot += dy[e] * xh;
+                v[e] = xh;
+            }
+            for (int msk = 1; msk < lph; msk <<= 1) dot += __shfl_xor(dot, msk);
+            dot /= (float)hd;
+            if (act) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = inv * (dy[e] - v[e] * dot);
+                od_st8(dqkv + m * lddqkv + (size_t)slot * hd + c8 * 8, o);
+            }
+        }
+    }
+    const int c8 = lane % lph;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        atomicAdd(&sdw[0][c8 * 8 + e], aq[e]);
+        atomicAdd(&sdw[1][c8 * 8 + e], ak[e]);
+    }
+    __syncthreads();
+    if (threadIdx.x < hd) {
+        atomicAdd(dwq + threadIdx.x, sdw[0][threadIdx.x]);
+        atomicAdd(dwk + threadIdx.x, sdw[1][threadIdx.x]);
+    }
+}
+
+__global__ void rope_table_kernel(float* __restrict__ table, int L, int hd) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = hd / 2;
+    if (i >= (long)L * half) return;
+    const int l = (int)(i / half), j = (int)(i % half);
+    // inv_freq = 10000^(-2j/hd) computed like the reference: float pow, then float product l*inv_freq
+    const float inv_freq = powf(10000.0f, -(float)(2 * j) / (float)hd);
+    const float ang = (float)l * inv_freq;
+    table[2 * i] = cosf(ang);
+    table[2 * i + 1] = sinf(ang);
+}
+
+inline int nch_for(int C) { return (C + 511) / 512; }
+
+}  // namespace
+
+#define DISPATCH_T_NCH(DT, NCHV, CALL)                                          \
+    do {                                                                        \
+        if ((DT) == OD_BF16) {                                                  \
+            typedef bf16_t T_;                                                  \
+            if ((NCHV) == 1) { constexpr int N_ = 1; CALL; }                    \
+            else if ((NCHV) == 2) { constexpr int N_ = 2; CALL; }               \
+            else if ((NCHV) == 3) { constexpr int N_ = 3; CALL; }               \
+            else return OD_ERR_UNSUPPORTED;                                     \
+        } else if ((DT) == OD_F32) {                                            \
+            typedef float T_;                                                   \
+            if ((NCHV) == 1) { constexpr int N_ = 1; CALL; }                    \
+            else if ((NCHV) == 2) { constexpr int N_ = 2; CALL; }               \
+            else if ((NCHV) == 3) { constexpr int N_ = 3; CALL; }               \
+            else return OD_ERR_UNSUPPORTED;                                     \
+        } else return OD_ERR_ARG;                                               \
+    } while (0)
+
+extern "C" int od_rmsnorm_film(int dtype, const void* x, int ldx, const float* ssg, const void* cl, int ldcl, int cl_bcast,
+                               void* h, int ldh, float* inv_rms, int B, int L, int C, float eps, void* stream) {
+    if (C % 8 || ldx % 8 || ldh % 8 || (cl && ldcl % 8)) return OD_ERR_ALIGN;
+    const long M = (long)B * L;
+    dim3 grid((unsigned)((M + 3) / 4));
+    DISPATCH_T_NCH(dtype, nch_for(C),
+        OD_LAUNCH((rmsnorm_film_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, ssg, (const T_*)cl, ldcl,
+                  cl_bcast, (T_*)h, ldh, inv_rms, B, L, C, eps));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_rmsnorm_film_bwd(int dtype, const void* x, int ldx, const float* inv_rms, const float* ssg, const void* dh,
+                                   int lddh, void* dres, int lddres, float* dssg, int B, int L, int C, void* stream) {
+    if (C % 8 || ldx % 8 || lddh % 8 || lddres % 8) return OD_ERR_ALIGN;
+    dim3 grid((L + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD), B);
+    DISPATCH_T_NCH(dtype, nch_for(C),
+        OD_LAUNCH((rmsnorm_film_bwd_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, inv_rms, ssg,
+                  (const T_*)dh, lddh, (T_*)dres, lddres, dssg, B, L, C));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_rmsnorm_gate_residual(int dtype, const void* x, int ldx, const void* h, int ldh, const float* ssg, void* xo,
+                                        int ldxo, float* inv_rms, int B, int L, int C, float eps, void* stream) {
+    if (C % 8 || ldx % 8 || ldh % 8 || ldxo % 8) return OD_ERR_ALIGN;
+    const long M = (long)B * L;
+    dim3 grid((unsigned)((M + 3) / 4));
+    DISPATCH_T_NCH(dtype, nch_for(C),
+        OD_LAUNCH((rmsnorm_gate_res_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, (const T_*)h, ldh, ssg,
+                  (T_*)xo, ldxo, inv_rms, B, L, C, eps));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_rmsnorm_gate_residual_bwd(int dtype, const void* h, int ldh, const float* inv_rms, const float* ssg,
+                                            const void* dy, int lddy, void* dh, int lddh, float* dssg, int B, int L, int C,
+                                            void* stream) {
+    if (C % 8 || ldh % 8 || lddy % 8 || lddh % 8) return OD_ERR_ALIGN;
+    dim3 grid((L + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD), B);
+    DISPATCH_T_NCH(dtype, nch_for(C),
+        OD_LAUNCH((rmsnorm_gate_res_bwd_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)h, ldh, inv_rms, ssg,
+                  (const T_*)dy, lddy, (T_*)dh, lddh, dssg, B, L, C));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_swiglu_rmsnorm(int dtype, const void* vg, int ldvg, void* hh, int ldhh, float* inv_rms, int M, int Hf, int Hp,
+                                 float eps, void* stream) {
+    if (Hp % 8 || ldvg % 8 || ldhh % 8 || Hf > Hp) return OD_ERR_ALIGN;
+    dim3 grid((unsigned)((M + 3) / 4));
+    DISPATCH_T_NCH(dtype, nch_for(Hp),
+        OD_LAUNCH((swiglu_rmsnorm_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)vg, ldvg, (T_*)hh, ldhh, inv_rms,
+                  (long)M, Hf, Hp, eps));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_swiglu_rmsnorm_bwd(int dtype, const void* vg, int ldvg, const float* inv_rms, const void* dhh, int lddhh,
+                                     void* dvg, int lddvg, int M, int Hf, int Hp, void* stream) {
+    if (Hp % 8 || ldvg % 8 || lddhh % 8 || lddvg % 8 || Hf > Hp) return OD_ERR_ALIGN;
+    dim3 grid((unsigned)((M + 3) / 4));
+    DISPATCH_T_NCH(dtype, nch_for(Hp),
+        OD_LAUNCH((swiglu_rmsnorm_bwd_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)vg, ldvg, inv_rms,
+                  (const T_*)dhh, lddhh, (T_*)dvg, lddvg, (long)M, Hf, Hp));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_final_norm_proj_out(int dtype, const void* x, int ldx, const float* W, const float* bias, float* v,
+                                      float* inv_rms, int B, int L, int C, int E, float eps, void* stream) {
+    if (C % 8 || ldx % 8) return OD_ERR_ALIGN;
+    if (E > 8 || C > 1024) return OD_ERR_UNSUPPORTED;
+    const long M = (long)B * L;
+    dim3 grid((unsigned)((M + 3) / 4));
+    DISPATCH_T_NCH(dtype, nch_for(C),
+        OD_LAUNCH((final_proj_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, W, bias, v, inv_rms, B, L, C, E, eps));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_final_norm_proj_out_bwd(int dtype, const void* x, int ldx, const float* inv_rms, const float* W,
+                                          const float* dv, void* dx, int lddx, float* dW, float* db, int B, int L, int C, int E,
+                                          void* stream) {
+    if (C % 8 || ldx % 8 || lddx % 8) return OD_ERR_ALIGN;
+    if (E > 8 || C > 512) return OD_ERR_UNSUPPORTED;
+    dim3 grid((L + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD), B);
+    if (dtype == OD_BF16)
+        OD_LAUNCH((final_proj_bwd_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, inv_rms, W, dv,
+                  (bf16_t*)dx, lddx, dW, db, B, L, C, E);
+    else
+        OD_LAUNCH((final_proj_bwd_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, inv_rms, W, dv,
+                  (float*)dx, lddx, dW, db, B, L, C, E);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_rope_table(float* table, int L, int hd, void* stream) {
+    if (hd % 2 || L <= 0) return OD_ERR_ARG;
+    const long n = (long)L * (hd / 2);
+    OD_LAUNCH(rope_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, L, hd);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const float* wq, const float* wk, const float* table,
+                               void* qk_out, int ldo, int B, int L, int H, int hd, float eps, void* stream) {
+    if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
+    if (ldqkv % 8 || ldo % 8) return OD_ERR_ALIGN;
+    const long M = (long)B * L;
+    dim3 grid((unsigned)((M + 3) / 4));
+    if (dtype == OD_BF16)
+        OD_LAUNCH((qk_norm_rope_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,
+                  (bf16_t*)qk_out, ldo, B, L, H, hd, eps);
+    else
+        OD_LAUNCH((qk_norm_rope_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, ldqkv, wq, wk, table,
+                  (float*)qk_out, ldo, B, L, H, hd, eps);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const float* wq, const float* wk, const float* table,
+                                   const void* dqk, int lddqk, void* dqkv, int lddqkv, float* dwq, float* dwk, int B, int L,
+                                   int H, int hd, float eps, void* stream) {
+    if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
+    if (ldqkv % 8 || lddqk % 8 || lddqkv % 8) return OD_ERR_ALIGN;
+    const long M = (long)B * L;
+    dim3 grid((unsigned)((M + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD)));
+    if (dtype == OD_BF16)
+        OD_LAUNCH((qk_norm_rope_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,
+                  (const bf16_t*)dqk, lddqk, (bf16_t*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps);
+    else
+        OD_LAUNCH((qk_norm_rope_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, ldqkv, wq, wk, table,
+                  (const float*)dqk, lddqk, (float*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps);
+    OD_CHECK_LAUNCH();
+    return 0;
+}

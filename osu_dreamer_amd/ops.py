@@ -1,0 +1,298 @@
+"""Thin torch-tensor front end over the C ABI (include/osu_dreamer_hip.h).
+
+Each function forwards raw pointers/sizes to one `od_*` entry point on the current HIP
+stream.  Tensors are only storage here: no arithmetic is done with torch ops.
+Activations are frame-major 2-D tensors [M = B*L, C] (see csrc/od_common.h).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import OD_ACT_NONE, OD_ACT_SILU, OD_BF16, OD_EPI_NONE, OD_EPI_SILU, OD_F32
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return OD_F32
+    if dtype == torch.bfloat16:
+        return OD_BF16
+    raise TypeError(f"unsupported compute dtype {dtype}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "need a row-major 2-D view"
+    return t.stride(0)
+
+
+def _f32(*ts):
+    for t in ts:
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous()), "expected contiguous fp32"
+
+
+# ---------------------------------------------------------------- GEMMs
+def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False):
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and tuple(C.shape) == (M, N)
+    assert A.dtype == W.dtype == C.dtype
+    _f32(bias)
+    _lib.lib().od_gemm_nt(dt_code(A.dtype), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
+                          epilogue, int(accumulate), _stream(A))
+
+
+def gemm_tn(G, A, dW, n_cols=None, k_cols=None):
+    """dW[N,K] += G[:, :N]^T A[:, :K];  dW is any fp32 tensor viewed as [N, K] rows."""
+    M = G.shape[0]
+    N = n_cols if n_cols is not None else G.shape[1]
+    K = k_cols if k_cols is not None else A.shape[1]
+    assert dW.dtype == torch.float32 and dW.is_contiguous() and dW.numel() == N * K
+    _lib.lib().od_gemm_tn(dt_code(G.dtype), _p(G), _ld(G), _p(A), _ld(A), _p(dW), K, M, N, K, _stream(G))
+
+
+def colsum(G, out, n_cols=None):
+    M = G.shape[0]
+    N = n_cols if n_cols is not None else G.shape[1]
+    _f32(out)
+    _lib.lib().od_colsum(dt_code(G.dtype), _p(G), _ld(G), _p(out), M, N, _stream(G))
+
+
+def pack_weight(src, dst, transpose=False, row_map=None):
+    """dst (compute dtype, zero padded) from the fp32 master `src` viewed as [N, K]."""
+    N = src.shape[0]
+    K = src.numel() // N
+    _f32(src)
+    if transpose:
+        Kp, Np = dst.shape
+    else:
+        Np, Kp = dst.shape
+    assert dst.is_contiguous()
+    _lib.lib().od_pack_weight(dt_code(dst.dtype), _p(src), N, K, _p(dst), Np, Kp, int(transpose), _p(row_map), _stream(src))
+
+
+# ---------------------------------------------------------------- per-sample linears (fp32)
+def linear_small(x, W, b, out, pre=None, act=OD_ACT_NONE):
+    B, K = x.shape
+    N = W.shape[0]
+    _f32(x, W, b, out, pre)
+    _lib.lib().od_linear_small(_p(x), _p(W), _p(b), _p(out), _p(pre), B, N, K, act, _stream(x))
+
+
+def linear_small_bwd(x, W, pre, dout, dpre, dW, db, dx, accumulate_dx, act=OD_ACT_NONE):
+    B, K = x.shape
+    N = W.shape[0]
+    _f32(x, W, pre, dout, dpre, dW, db, dx)
+    _lib.lib().od_linear_small_bwd(_p(x), _p(W), _p(pre), _p(dout), _p(dpre), _p(dW), _p(db), _p(dx),
+                                   int(accumulate_dx), B, N, K, act, _stream(x))
+
+
+# ---------------------------------------------------------------- boundary / layout
+def cl_to_frames(src, dst):
+    B, C, L = src.shape
+    _f32(src)
+    _lib.lib().od_cl_to_frames(dt_code(dst.dtype), _p(src), _p(dst), _ld(dst), B, C, L, _stream(src))
+
+
+def proj_in(xt, W, bias, x):
+    B, E, L = xt.shape
+    D = x.shape[1]
+    _f32(xt, W, bias)
+    _lib.lib().od_proj_in(dt_code(x.dtype), _p(xt), _p(W), _p(bias), _p(x), _ld(x), B, E, L, D, _stream(xt))
+
+
+def proj_in_bwd(xt, dx, dW, db):
+    B, E, L = xt.shape
+    D = dx.shape[1]
+    _f32(xt, dW, db)
+    _lib.lib().od_proj_in_bwd(dt_code(dx.dtype), _p(xt), _p(dx), _ld(dx), _p(dW), _p(db), B, E, L, D, _stream(xt))
+
+
+def silu(x, y):
+    assert x.is_contiguous() and y.is_contiguous()
+    _lib.lib().od_silu(dt_code(x.dtype), _p(x), _p(y), x.numel(), _stream(x))
+
+
+def silu_bwd(x, dy, dx):
+    assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous()
+    _lib.lib().od_silu_bwd(dt_code(x.dtype), _p(x), _p(dy), _p(dx), x.numel(), _stream(x))
+
+
+# ---------------------------------------------------------------- norm / modulation
+def rmsnorm_film(x, ssg, cl, cl_bcast, h, inv_rms, B, L, eps=1e-6):
+    C = x.shape[1]
+    _f32(ssg, inv_rms)
+    _lib.lib().od_rmsnorm_film(dt_code(x.dtype), _p(x), _ld(x), _p(ssg), _p(cl), _ld(cl) if cl is not None else 0,
+                               int(cl_bcast), _p(h), _ld(h), _p(inv_rms), B, L, C, eps, _stream(x))
+
+
+def rmsnorm_film_bwd(x, inv_rms, ssg, dh, dres, dssg, B, L):
+    C = x.shape[1]
+    _f32(ssg, inv_rms, dssg)
+    _lib.lib().od_rmsnorm_film_bwd(dt_code(x.dtype), _p(x), _ld(x), _p(inv_rms), _p(ssg), _p(dh), _ld(dh), _p(dres),
+                                   _ld(dres), _p(dssg), B, L, C, _stream(x))
+
+
+def rmsnorm_gate_residual(x, h, ssg, xo, inv_rms, B, L, eps=1e-6):
+    C = x.shape[1]
+    _f32(ssg, inv_rms)
+    _lib.lib().od_rmsnorm_gate_residual(dt_code(x.dtype), _p(x), _ld(x), _p(h), _ld(h), _p(ssg), _p(xo), _ld(xo),
+                                        _p(inv_rms), B, L, C, eps, _stream(x))
+
+
+def rmsnorm_gate_residual_bwd(h, inv_rms, ssg, dy, dh, dssg, B, L):
+    C = h.shape[1]
+    _f32(ssg, inv_rms, dssg)
+    _lib.lib().od_rmsnorm_gate_residual_bwd(dt_code(h.dtype), _p(h), _ld(h), _p(inv_rms), _p(ssg), _p(dy), _ld(dy),
+                                            _p(dh), _ld(dh), _p(dssg), B, L, C, _stream(h))
+
+
+# ---------------------------------------------------------------- attention
+def rope_table(table, L, hd):
+    _f32(table)
+    _lib.lib().od_rope_table(_p(table), L, hd, _stream(table))
+
+
+def qk_norm_rope(qkv, wq, wk, table, qk_out, B, L, H, hd, eps):
+    _f32(wq, wk, table)
+    _lib.lib().od_qk_norm_rope(dt_code(qkv.dtype), _p(qkv), _ld(qkv), _p(wq), _p(wk), _p(table), _p(qk_out),
+                               _ld(qk_out), B, L, H, hd, eps, _stream(qkv))
+
+
+def qk_norm_rope_bwd(qkv, wq, wk, table, dqk, dqkv, dwq, dwk, B, L, H, hd, eps):
+    _f32(wq, wk, table, dwq, dwk)
+    _lib.lib().od_qk_norm_rope_bwd(dt_code(qkv.dtype), _p(qkv), _ld(qkv), _p(wq), _p(wk), _p(table), _p(dqk), _ld(dqk),
+                                   _p(dqkv), _ld(dqkv), _p(dwq), _p(dwk), B, L, H, hd, eps, _stream(qkv))
+
+
+def flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale):
+    _f32(lse)
+    _lib.lib().od_flash_attn_fwd(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(lse),
+                                 B, H, L, hd, scale, _stream(q))
+
+
+def flash_attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, L, hd, scale):
+    _f32(lse, delta)
+    _lib.lib().od_flash_attn_bwd(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(do),
+                                 _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv),
+                                 B, H, L, hd, scale, _stream(q))
+
+
+# ---------------------------------------------------------------- feed-forward
+def dwconv(x, w, bias, y, B, L, ksize):
+    C = x.shape[1]
+    _f32(w, bias)
+    _lib.lib().od_dwconv(dt_code(x.dtype), _p(x), _ld(x), _p(w), _p(bias), _p(y), _ld(y), B, L, C, ksize, _stream(x))
+
+
+def dwconv_bwd(x, w, dy, dx, dw, db, B, L, ksize):
+    C = x.shape[1]
+    _f32(w, dw, db)
+    _lib.lib().od_dwconv_bwd(dt_code(x.dtype), _p(x), _ld(x), _p(w), _p(dy), _ld(dy), _p(dx), _ld(dx), _p(dw), _p(db),
+                             B, L, C, ksize, _stream(x))
+
+
+def swiglu_rmsnorm(vg, hh, inv_rms, Hf, Hp, eps=1e-6):
+    _f32(inv_rms)
+    _lib.lib().od_swiglu_rmsnorm(dt_code(vg.dtype), _p(vg), _ld(vg), _p(hh), _ld(hh), _p(inv_rms), vg.shape[0], Hf, Hp,
+                                 eps, _stream(vg))
+
+
+def swiglu_rmsnorm_bwd(vg, inv_rms, dhh, dvg, Hf, Hp):
+    _f32(inv_rms)
+    _lib.lib().od_swiglu_rmsnorm_bwd(dt_code(vg.dtype), _p(vg), _ld(vg), _p(inv_rms), _p(dhh), _ld(dhh), _p(dvg),
+                                     _ld(dvg), vg.shape[0], Hf, Hp, _stream(vg))
+
+
+# ---------------------------------------------------------------- heads
+def final_norm_proj_out(x, W, bias, v, inv_rms, B, L, eps=1e-6):
+    C = x.shape[1]
+    E = W.shape[0]
+    _f32(W, bias, v, inv_rms)
+    _lib.lib().od_final_norm_proj_out(dt_code(x.dtype), _p(x), _ld(x), _p(W), _p(bias), _p(v), _p(inv_rms), B, L, C, E,
+                                      eps, _stream(x))
+
+
+def final_norm_proj_out_bwd(x, inv_rms, W, dv, dx, dW, db, B, L):
+    C = x.shape[1]
+    E = W.shape[0]
+    _f32(W, dv, inv_rms, dW, db)
+    _lib.lib().od_final_norm_proj_out_bwd(dt_code(x.dtype), _p(x), _ld(x), _p(inv_rms), _p(W), _p(dv), _p(dx), _ld(dx),
+                                          _p(dW), _p(db), B, L, C, E, _stream(x))
+
+
+def uhead_fwd(xt, w, fsum, U):
+    """w: the eight u_head tensors (w0,b0,w1,b1,w3,b3,w4,b4)."""
+    B, E, L = xt.shape
+    _f32(xt, fsum, *w)
+    _lib.lib().od_uhead_fwd(_p(xt), *[_p(t) for t in w], _p(fsum), B, E, L, U, _stream(xt))
+
+
+def uhead_bwd(xt, w, dfm, g, U):
+    B, E, L = xt.shape
+    _f32(xt, dfm, *w, *g)
+    _lib.lib().od_uhead_bwd(_p(xt), *[_p(t) for t in w], _p(dfm), *[_p(t) for t in g], B, E, L, U, _stream(xt))
+
+
+def uhead_tail(fsum, mod, w_out, b_out, u, L, u_scale):
+    B, U = fsum.shape
+    _f32(fsum, mod, w_out, b_out, u)
+    _lib.lib().od_uhead_tail(_p(fsum), _p(mod), _p(w_out), _p(b_out), _p(u), B, U, L, u_scale, _stream(fsum))
+
+
+def uhead_tail_bwd(fsum, mod, w_out, b_out, du, dfm, dmod, dw_out, db_out, L, u_scale):
+    B, U = fsum.shape
+    _f32(fsum, mod, w_out, b_out, du, dfm, dmod, dw_out, db_out)
+    _lib.lib().od_uhead_tail_bwd(_p(fsum), _p(mod), _p(w_out), _p(b_out), _p(du), _p(dfm), _p(dmod), _p(dw_out),
+                                 _p(db_out), B, U, L, u_scale, _stream(fsum))
+
+
+# ---------------------------------------------------------------- loss / sampler
+def make_xt(x0, x1, t, xt, dsq):
+    B, E, L = x0.shape
+    _f32(x0, x1, t, xt, dsq)
+    _lib.lib().od_make_xt(_p(x0), _p(x1), _p(t), _p(xt), _p(dsq), B, E, L, _stream(x0))
+
+
+def loss_grad(xt, x1, u, v, dsq, dv, sums, c0, osl_w, del_w):
+    B, E, L = xt.shape
+    _f32(xt, x1, u, v, dsq, dv, sums)
+    _lib.lib().od_loss_grad(_p(xt), _p(x1), _p(u), _p(v), _p(dsq), _p(dv), _p(sums), B, E, L, c0, osl_w, del_w, _stream(xt))
+
+
+def loss_finalize(sums, dsq, u, out, du, c0, osl_w, del_w):
+    B = u.shape[0]
+    _f32(sums, dsq, u, out, du)
+    _lib.lib().od_loss_finalize(_p(sums), _p(dsq), _p(u), _p(out), _p(du), B, c0, osl_w, del_w, _stream(u))
+
+
+def sampler_step(x, u, v, eta):
+    B, E, L = x.shape
+    _f32(x, u, v, eta)
+    _lib.lib().od_sampler_step(_p(x), _p(u), _p(v), _p(eta), B, E, L, _stream(x))
+
+
+def sampler_eta(u, eta, c0, num_steps):
+    _f32(u, eta)
+    _lib.lib().od_sampler_eta(_p(u), _p(eta), u.shape[0], c0, num_steps, _stream(u))
+
+
+# ---------------------------------------------------------------- optimizer
+def sqnorm(g, out):
+    _f32(g, out)
+    _lib.lib().od_sqnorm(_p(g), g.numel(), _p(out), _stream(g))
+
+
+def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, weight_decay, step, ema_decay, ema_mode, gnorm_sq, max_norm):
+    _f32(p, g, m, v, ema, gnorm_sq)
+    _lib.lib().od_adamw_ema(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                            ema_decay, ema_mode, _p(gnorm_sq), max_norm, _stream(p))

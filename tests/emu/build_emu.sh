@@ -1,0 +1,18 @@
+#!/bin/bash
+# Host build of the SAME kernel sources against the SIMT emulator (test infrastructure).
+set -e
+cd "$(dirname "$0")"
+CS=../../osu_dreamer_amd/csrc
+OUT=libod_emu.so
+mkdir -p build
+OBJS=""
+for s in gemm rowops misc heads optim attn; do
+  o=build/$s.o
+  if [ ! -f "$o" ] || [ "$CS/$s.hip" -nt "$o" ] || [ "$CS/od_common.h" -nt "$o" ] || [ emu_hip.h -nt "$o" ]; then
+    /opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fPIC -DOD_EMU -I. -I$CS -Wno-unused-value -c $CS/$s.hip -o $o &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+/opt/rocm/lib/llvm/bin/clang++ -shared -fPIC $OBJS -o $OUT
+echo "built $OUT"

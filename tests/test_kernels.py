@@ -1,0 +1,380 @@
+"""Per-kernel parity: every od_* entry point against the oracle's op on the same seeded
+inputs, in fp32 (tolerance 2e-5 rel-L2) and bf16 (2e-2).  Runs on the emulator build
+(CPU) and, marked gpu, on the MI355X through the real C ABI."""
+import math
+
+import pytest
+import torch
+
+from oracle import denoiser_oracle as O
+from osu_dreamer_amd import ops
+from kernel_backend import dev, frames, unframes, rel_l2, TOL  # noqa: F401
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def leaf(t):
+    return t.detach().float().cpu().clone().requires_grad_()
+
+
+def mk(shape, g, dev, dtype=torch.float32, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (128, 128, 64), (77, 24, 16), (300, 384, 192)])
+def test_gemm_nt(dev, dtype, M, N, K):
+    g = torch.Generator().manual_seed(1)
+    A, W, b = mk((M, K), g, dev, dtype), mk((N, K), g, dev, dtype, 0.2), mk((N,), g, dev)
+    C = torch.zeros(M, N, dtype=dtype, device=dev)
+    ops.gemm_nt(A, W, b, C)
+    ref = A.float().cpu() @ W.float().cpu().t() + b.cpu()
+    assert rel_l2(C.float(), ref) < TOL[dtype]
+    ops.gemm_nt(A, W, b, C, epilogue=ops.OD_EPI_SILU)
+    assert rel_l2(C.float(), O.silu(ref)) < TOL[dtype]
+    C0 = mk((M, N), g, dev, dtype)
+    C = C0.clone()
+    ops.gemm_nt(A, W, None, C, accumulate=True)
+    assert rel_l2(C.float(), ref - b.cpu() + C0.float().cpu()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (64, 16, 24), (1000, 130, 170)])
+def test_gemm_tn_colsum(dev, dtype, M, N, K):
+    g = torch.Generator().manual_seed(2)
+    ldg, lda = (N + 7) // 8 * 8 + 8, (K + 7) // 8 * 8
+    Gf = mk((M, ldg), g, dev, dtype)
+    Af = mk((M, lda), g, dev, dtype)
+    dW0 = mk((N, K), g, dev)
+    dW = dW0.clone()
+    ops.gemm_tn(Gf, Af, dW, n_cols=N, k_cols=K)
+    ref = Gf.float().cpu()[:, :N].t() @ Af.float().cpu()[:, :K] + dW0.cpu()
+    assert rel_l2(dW, ref) < TOL[dtype]
+    out = torch.zeros(N, device=dev)
+    ops.colsum(Gf, out, n_cols=N)
+    assert rel_l2(out, Gf.float().cpu()[:, :N].sum(0)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_weight(dev, dtype):
+    g = torch.Generator().manual_seed(3)
+    src = mk((10, 6, 1), g, dev)
+    dst = torch.full((16, 8), 7.0, dtype=dtype, device=dev)
+    ops.pack_weight(src, dst)
+    ref = torch.zeros(16, 8); ref[:10, :6] = src.cpu()[:, :, 0]
+    assert torch.equal(dst.float().cpu(), ref.to(dtype).float())
+    dstT = torch.full((8, 16), 7.0, dtype=dtype, device=dev)
+    ops.pack_weight(src, dstT, transpose=True)
+    assert torch.equal(dstT.float().cpu(), ref.t().to(dtype).float())
+    rm = torch.tensor([0, 1, 2, -1, 5, 6, 7, -1], dtype=torch.int32, device=dev)
+    d2 = torch.full((8, 8), 7.0, dtype=dtype, device=dev)
+    ops.pack_weight(src, d2, row_map=rm)
+    ref2 = torch.zeros(8, 8)
+    for i, s in enumerate(rm.tolist()):
+        if s >= 0:
+            ref2[i, :6] = src.cpu()[s, :, 0]
+    assert torch.equal(d2.float().cpu(), ref2.to(dtype).float())
+
+
+def test_linear_small(dev):
+    g = torch.Generator().manual_seed(4)
+    B, N, K = 3, 50, 40
+    x, W, b, dout = mk((B, K), g, dev), mk((N, K), g, dev, scale=.3), mk((N,), g, dev), mk((B, N), g, dev)
+    for act in (ops.OD_ACT_NONE, ops.OD_ACT_SILU):
+        out, pre = torch.zeros(B, N, device=dev), torch.zeros(B, N, device=dev)
+        ops.linear_small(x, W, b, out, pre, act)
+        xr, Wr, br = leaf(x), leaf(W), leaf(b)
+        ref = xr @ Wr.t() + br
+        if act:
+            ref = O.silu(ref)
+        assert rel_l2(out, ref) < 1e-5
+        ref.backward(dout.cpu())
+        dW, db, dx, dpre = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev), torch.ones(B, K, device=dev), torch.zeros(B, N, device=dev)
+        ops.linear_small_bwd(x, W, pre, dout, dpre, dW, db, dx, True, act)
+        assert rel_l2(dW, Wr.grad) < 1e-5 and rel_l2(db, br.grad) < 1e-5 and rel_l2(dx - 1, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_projin_silu(dev, dtype):
+    g = torch.Generator().manual_seed(5)
+    B, C, L, E, D = 2, 24, 70, 6, 64
+    src = mk((B, C, L), g, dev)
+    dst = torch.zeros(B * L, C, dtype=dtype, device=dev)
+    ops.cl_to_frames(src, dst)
+    assert torch.equal(dst.float().cpu(), frames(src.cpu()).to(dtype).float())
+    xt, W, b = mk((B, E, L), g, dev), mk((D, E, 1), g, dev), mk((D,), g, dev)
+    x = torch.zeros(B * L, D, dtype=dtype, device=dev)
+    ops.proj_in(xt, W, b, x)
+    ref = O.pointwise_conv(xt.cpu(), W.cpu(), b.cpu())
+    assert rel_l2(x.float(), frames(ref)) < TOL[dtype]
+    dx = mk((B * L, D), g, dev, dtype)
+    dW, db = torch.zeros(D, E, 1, device=dev), torch.zeros(D, device=dev)
+    ops.proj_in_bwd(xt, dx, dW, db)
+    dxr = unframes(dx.float().cpu(), B, L)
+    assert rel_l2(dW[:, :, 0], torch.einsum("bdl,bel->de", dxr, xt.cpu())) < TOL[dtype]
+    assert rel_l2(db, dxr.sum((0, 2))) < TOL[dtype]
+    y = torch.zeros_like(x)
+    ops.silu(x, y)
+    assert rel_l2(y.float(), O.silu(x.float().cpu())) < TOL[dtype]
+    xr = leaf(x)
+    O.silu(xr).backward(dx.float().cpu())
+    d2 = torch.zeros_like(x)
+    ops.silu_bwd(x, dx, d2)
+    assert rel_l2(d2.float(), xr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,bcast", [(64, False), (512, True), (136, False)])
+def test_rmsnorm_film_and_gate(dev, dtype, C, bcast):
+    g = torch.Generator().manual_seed(6)
+    B, L = 2, 37
+    M = B * L
+    x, h = mk((M, C), g, dev, dtype), mk((M, C), g, dev, dtype)
+    ssg = mk((B, 3 * C), g, dev, scale=.5)
+    cl = mk((L if bcast else M, C), g, dev, dtype)
+    out = torch.zeros_like(x)
+    inv = torch.zeros(M, device=dev)
+    ops.rmsnorm_film(x, ssg, cl, bcast, out, inv, B, L)
+
+    def film(xr, ssgr, clr):
+        xb = unframes(xr, B, L)
+        sc, sh = ssgr[:, :C, None], ssgr[:, C:2 * C, None]
+        clb = unframes(clr, 1 if bcast else B, L)
+        return frames(O.rms_norm_channels(xb) * (1 + sc) + sh + clb)
+    xr, sr = leaf(x), leaf(ssg)
+    ref = film(xr, sr, cl.float().cpu())
+    assert rel_l2(out.float(), ref) < TOL[dtype]
+    dh = mk((M, C), g, dev, dtype)
+    ref.backward(dh.float().cpu())
+    dres0 = mk((M, C), g, dev, dtype)
+    dres = dres0.clone()
+    dssg = torch.zeros(B, 3 * C, device=dev)
+    ops.rmsnorm_film_bwd(x, inv, ssg, dh, dres, dssg, B, L)
+    assert rel_l2(dres.float() - dres0.float(), xr.grad) < 2.5 * TOL[dtype]
+    assert rel_l2(dssg[:, :2 * C], sr.grad[:, :2 * C]) < TOL[dtype]
+
+    xo = torch.zeros_like(x)
+    ops.rmsnorm_gate_residual(x, h, ssg, xo, inv, B, L)
+    hr, sr = leaf(h), leaf(ssg)
+    ref = x.float().cpu() + frames(O.rms_norm_channels(unframes(hr, B, L)) * sr[:, 2 * C:, None])
+    assert rel_l2(xo.float(), ref) < TOL[dtype]
+    ref.backward(dh.float().cpu())
+    dhh = torch.zeros_like(x)
+    dssg.zero_()
+    ops.rmsnorm_gate_residual_bwd(h, inv, ssg, dh, dhh, dssg, B, L)
+    assert rel_l2(dhh.float(), hr.grad) < TOL[dtype]
+    assert rel_l2(dssg[:, 2 * C:], sr.grad[:, 2 * C:]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,hd", [(2, 32), (16, 64), (3, 16)])
+def test_qk_norm_rope(dev, dtype, H, hd):
+    g = torch.Generator().manual_seed(7)
+    B, L = 2, 19
+    M, dh = B * L, H * hd
+    qkv = mk((M, 3 * dh), g, dev, dtype)
+    wq, wk = 1 + .2 * mk((hd,), g, dev), 1 + .2 * mk((hd,), g, dev)
+    table = torch.zeros(L, hd // 2, 2, device=dev)
+    ops.rope_table(table, L, hd)
+    inv_freq = 10000.0 ** (torch.arange(0, hd, 2).float() / -hd)
+    ang = torch.outer(torch.arange(L).float(), inv_freq)
+    assert rel_l2(table[..., 0], ang.cos()) < 1e-5 and rel_l2(table[..., 1], ang.sin()) < 1e-5
+    out = torch.zeros(M, 2 * dh, dtype=dtype, device=dev)
+    eps = torch.finfo(torch.float32).eps
+    ops.qk_norm_rope(qkv, wq, wk, table, out, B, L, H, hd, eps)
+
+    def ref_fn(qkvr, wqr, wkr):
+        t = qkvr.reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)   # (3,B,H,L,hd)
+        q = O.rope_half_split(O.head_rms_norm(t[0], wqr))
+        k = O.rope_half_split(O.head_rms_norm(t[1], wkr))
+        return torch.stack([q, k], 0).permute(1, 3, 0, 2, 4).reshape(M, 2 * dh)
+    qr, wqr, wkr = leaf(qkv), leaf(wq), leaf(wk)
+    ref = ref_fn(qr, wqr, wkr)
+    assert rel_l2(out.float(), ref) < TOL[dtype]
+    dqk = mk((M, 2 * dh), g, dev, dtype)
+    ref.backward(dqk.float().cpu())
+    dqkv = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
+    dwq, dwk = torch.zeros(hd, device=dev), torch.zeros(hd, device=dev)
+    ops.qk_norm_rope_bwd(qkv, wq, wk, table, dqk, dqkv, dwq, dwk, B, L, H, hd, eps)
+    assert rel_l2(dqkv.float()[:, :2 * dh], qr.grad[:, :2 * dh]) < TOL[dtype]
+    assert rel_l2(dwq, wqr.grad) < TOL[dtype] and rel_l2(dwk, wkr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,L,hd", [(1, 2, 150, 32), (2, 1, 64, 64), (1, 1, 257, 64), (1, 1, 5, 32)])
+def test_flash_attention(dev, dtype, B, H, L, hd):
+    g = torch.Generator().manual_seed(8)
+    M, dh = B * L, H * hd
+    qk = mk((M, 2 * dh), g, dev, dtype)
+    qkv = mk((M, 3 * dh), g, dev, dtype)
+    q, k, v = qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:]
+    o = torch.zeros(M, dh, dtype=dtype, device=dev)
+    lse = torch.zeros(B, H, L, device=dev)
+    scale = 1 / math.sqrt(hd)
+    ops.flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale)
+
+    def heads(t):   # [M, dh] -> (B,H,L,hd)
+        return t.reshape(B, L, H, hd).permute(0, 2, 1, 3)
+    qr, kr, vr = (leaf(t) for t in (q, k, v))
+    s = heads(qr) @ heads(kr).transpose(-1, -2) * scale
+    ref = (torch.softmax(s, -1) @ heads(vr)).permute(0, 2, 1, 3).reshape(M, dh)
+    assert rel_l2(o.float(), ref) < TOL[dtype]
+    assert rel_l2(lse, torch.logsumexp(s, -1)) < 1e-2 if dtype == torch.bfloat16 else 1e-5
+    do = mk((M, dh), g, dev, dtype)
+    ref.backward(do.float().cpu())
+    dq, dk, dv = (torch.zeros(M, dh, dtype=dtype, device=dev) for _ in range(3))
+    delta = torch.zeros(B, H, L, device=dev)
+    ops.flash_attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, L, hd, scale)
+    tol = 1.5 * TOL[dtype]
+    assert rel_l2(dv.float(), vr.grad) < tol
+    assert rel_l2(dk.float(), kr.grad) < tol
+    assert rel_l2(dq.float(), qr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ks", [3, 5])
+def test_dwconv(dev, dtype, ks):
+    g = torch.Generator().manual_seed(9)
+    B, L, C = 2, 75, 24
+    x = mk((B * L, C), g, dev, dtype)
+    w, b = mk((C, 1, ks), g, dev, scale=.4), mk((C,), g, dev)
+    y = torch.zeros_like(x)
+    ops.dwconv(x, w, b, y, B, L, ks)
+    xr, wr, br = leaf(x), leaf(w), leaf(b)
+    ref = frames(O.depthwise_conv(unframes(xr, B, L), wr, br))
+    assert rel_l2(y.float(), ref) < TOL[dtype]
+    dy = mk((B * L, C), g, dev, dtype)
+    ref.backward(dy.float().cpu())
+    dx, dw, db = torch.zeros_like(x), torch.zeros(C, 1, ks, device=dev), torch.zeros(C, device=dev)
+    ops.dwconv_bwd(x, w, dy, dx, dw, db, B, L, ks)
+    assert rel_l2(dx.float(), xr.grad) < TOL[dtype]
+    assert rel_l2(dw, wr.grad) < TOL[dtype] and rel_l2(db, br.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Hf,Hp", [(170, 192), (1365, 1408)])
+def test_swiglu_rmsnorm(dev, dtype, Hf, Hp):
+    g = torch.Generator().manual_seed(10)
+    M = 9
+    vg = torch.zeros(M, 2 * Hp, dtype=dtype, device=dev)
+    vg[:, :Hf] = mk((M, Hf), g, dev, dtype)
+    vg[:, Hp:Hp + Hf] = mk((M, Hf), g, dev, dtype)
+    hh = torch.zeros(M, Hp, dtype=dtype, device=dev)
+    inv = torch.zeros(M, device=dev)
+    ops.swiglu_rmsnorm(vg, hh, inv, Hf, Hp)
+    vr = leaf(vg)
+    ref = O.rms_norm_channels(vr[:, :Hf] * O.silu(vr[:, Hp:Hp + Hf]))
+    assert rel_l2(hh.float()[:, :Hf], ref) < TOL[dtype]
+    assert float(hh.float()[:, Hf:].abs().max()) == 0.0
+    dhh = torch.zeros(M, Hp, dtype=dtype, device=dev)
+    dhh[:, :Hf] = mk((M, Hf), g, dev, dtype)
+    ref.backward(dhh.float().cpu()[:, :Hf])
+    dvg = torch.zeros_like(vg)
+    ops.swiglu_rmsnorm_bwd(vg, inv, dhh, dvg, Hf, Hp)
+    assert rel_l2(dvg.float(), vr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_final_norm_proj_out(dev, dtype):
+    g = torch.Generator().manual_seed(11)
+    B, L, C, E = 2, 45, 64, 6
+    x = mk((B * L, C), g, dev, dtype)
+    W, b = mk((E, C, 1), g, dev, scale=.3), mk((E,), g, dev)
+    v, inv = torch.zeros(B, E, L, device=dev), torch.zeros(B * L, device=dev)
+    ops.final_norm_proj_out(x, W, b, v, inv, B, L)
+    xr, Wr, br = leaf(x), leaf(W), leaf(b)
+    ref = O.pointwise_conv(O.rms_norm_channels(unframes(xr, B, L)), Wr, br)
+    assert rel_l2(v, ref) < 1e-5
+    dv = mk((B, E, L), g, dev)
+    ref.backward(dv.cpu())
+    dx, dW, db = torch.zeros_like(x), torch.zeros(E, C, 1, device=dev), torch.zeros(E, device=dev)
+    ops.final_norm_proj_out_bwd(x, inv, W, dv, dx, dW, db, B, L)
+    assert rel_l2(dx.float(), xr.grad) < TOL[dtype]
+    assert rel_l2(dW, Wr.grad) < 1e-5 and rel_l2(db, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("U,L", [(16, 77), (64, 40), (64, 301)])
+def test_uhead(dev, U, L):
+    g = torch.Generator().manual_seed(12)
+    B, E = 2, 6
+    names = ["u_head.0", "u_head.1", "u_head.3", "u_head.4"]
+    shapes = {"u_head.0": (E, 1, 3), "u_head.1": (U, E, 1), "u_head.3": (U, 1, 3), "u_head.4": (U, U, 1)}
+    P = {}
+    for n in names:
+        P[n + ".weight"] = mk(shapes[n], g, dev, scale=.5)
+        P[n + ".bias"] = mk((shapes[n][0],), g, dev, scale=.3)
+    xt = mk((B, E, L), g, dev)
+    mod, w_out, b_out = mk((B, 2 * U), g, dev, scale=.3), mk((1, U), g, dev, scale=.3), mk((1,), g, dev)
+    wlist = [P[n + s] for n in names for s in (".weight", ".bias")]
+    fsum, u = torch.zeros(B, U, device=dev), torch.zeros(B, device=dev)
+    ops.uhead_fwd(xt, wlist, fsum, U)
+    ops.uhead_tail(fsum, mod, w_out, b_out, u, L, 3.4641016)
+    Pr = {k: leaf(v) for k, v in P.items()}
+    modr, wor, bor = leaf(mod), leaf(w_out), leaf(b_out)
+    f = O.u_head(xt.cpu(), Pr).mean(-1)
+    assert rel_l2(fsum / L, f) < 1e-5
+    fm = f * (1 + modr[:, :U]) + modr[:, U:]
+    uref = 3.4641016 * torch.nn.functional.softplus(fm @ wor.t() + bor).squeeze(-1)
+    assert rel_l2(u, uref) < 1e-5
+    du = mk((B,), g, dev)
+    uref.backward(du.cpu())
+    dfm, dmod = torch.zeros(B, U, device=dev), torch.zeros(B, 2 * U, device=dev)
+    dwo, dbo = torch.zeros(1, U, device=dev), torch.zeros(1, device=dev)
+    ops.uhead_tail_bwd(fsum, mod, w_out, b_out, du, dfm, dmod, dwo, dbo, L, 3.4641016)
+    assert rel_l2(dmod, modr.grad) < 1e-5 and rel_l2(dwo, wor.grad) < 1e-5 and rel_l2(dbo, bor.grad) < 1e-5
+    grads = [torch.zeros_like(t) for t in wlist]
+    ops.uhead_bwd(xt, wlist, dfm, grads, U)
+    for t, gr, n in zip(wlist, grads, [n + s for n in names for s in (".weight", ".bias")]):
+        assert rel_l2(gr, Pr[n].grad) < 2e-5, n
+
+
+def test_loss_and_sampler(dev):
+    g = torch.Generator().manual_seed(13)
+    B, E, L = 3, 6, 50
+    x0, x1, v = mk((B, E, L), g, dev), mk((B, E, L), g, dev), mk((B, E, L), g, dev)
+    t = torch.tensor([0.1, 0.5, 0.93], device=dev)
+    u = torch.tensor([1.5, 0.7, 2.2], device=dev)
+    c0, _ = O.distance_constants(E)
+    xt, dsq = torch.zeros_like(x0), torch.zeros(B, device=dev)
+    ops.make_xt(x0, x1, t, xt, dsq)
+    xtr = torch.lerp(x0.cpu(), x1.cpu(), t.cpu()[:, None, None])
+    assert rel_l2(xt, xtr) < 1e-6 and rel_l2(dsq, O.frame_dist_sq(xtr, x1.cpu())) < 1e-5
+    ur, vr = leaf(u), leaf(v)
+    d_sq = O.frame_dist_sq(xtr, x1.cpu())
+    ut = (d_sq + c0).sqrt()
+    osl = (O.frame_dist_sq(xtr - ur[:, None, None] * vr, x1.cpu()) / (d_sq + c0)).mean()
+    dl = O.frame_dist_sq(vr, (xtr - x1.cpu()) / ut[:, None, None]).mean()
+    loss = osl + 30 * dl
+    loss.backward()
+    dv, sums, out, du = torch.zeros_like(v), torch.zeros(B, 3, device=dev), torch.zeros(4, device=dev), torch.zeros(B, device=dev)
+    ops.loss_grad(xt, x1, u, v, dsq, dv, sums, c0, 1.0, 30.0)
+    ops.loss_finalize(sums, dsq, u, out, du, c0, 1.0, 30.0)
+    assert rel_l2(out[0], loss) < 1e-5 and rel_l2(out[1], osl) < 1e-5 and rel_l2(out[2], dl) < 1e-5
+    assert rel_l2(out[3], ((ur - ut) / ut).abs().mean()) < 1e-5
+    assert rel_l2(dv, vr.grad) < 1e-5 and rel_l2(du, ur.grad) < 1e-5
+    eta = torch.zeros(2, device=dev)
+    ops.sampler_eta(u, eta, c0, 8)
+    u0 = float(u.mean())
+    assert float(eta[0]) == pytest.approx(1 - (math.sqrt(c0) / max(u0, math.sqrt(c0) + 1e-6)) ** (1 / 8), rel=1e-5)
+    x = x0.clone()
+    ops.sampler_step(x, u, v, eta)
+    assert rel_l2(x, x0.cpu() - float(eta[0]) * u.cpu()[:, None, None] * v.cpu()) < 1e-6
+
+
+def test_optimizer(dev):
+    g = torch.Generator().manual_seed(14)
+    n = 1003
+    p, gr = mk((n,), g, dev), mk((n,), g, dev, scale=3.0)
+    m, v, ema = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    P, G = {"w": p.cpu().clone()}, {"w": gr.cpu().clone()}
+    Mo, Vo, Eo = {"w": torch.zeros(n)}, {"w": torch.zeros(n)}, {"w": torch.zeros(n)}
+    gn = torch.zeros(1, device=dev)
+    ops.sqnorm(gr, gn)
+    total, coef = O.clip_coef(G, 1.0)
+    assert float(gn.sqrt()) == pytest.approx(total, rel=1e-5)
+    for step in (1, 2, 3):
+        ops.adamw_ema(p, gr, m, v, ema, 3e-4, .9, .999, 1e-8, .01, step, .99, 1 if step == 1 else 2, gn, 1.0)
+        O.adamw_ema_step(P, G, Mo, Vo, Eo, step, 3e-4, clip=coef, first_ema=(step == 1))
+    assert torch.allclose(p.cpu(), P["w"], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(ema.cpu(), Eo["w"], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(v.cpu(), Vo["w"], rtol=1e-5, atol=1e-9)
