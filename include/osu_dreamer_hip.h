@@ -168,6 +168,10 @@ int od_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long 
                  float eps, float weight_decay, int step, float ema_decay, int ema_mode, const float* gnorm_sq,
                  float max_norm, void* stream);
 
+/* EMA only: mode 1 copy, mode 2 ema += (1-decay)*(p-ema).  replaces: train.py:125-126 when the
+ * average is updated outside the fused pass. */
+int od_ema_update(float* ema, const float* p, long n, float ema_decay, int ema_mode, void* stream);
+
 /* ---- hipGraph helpers for the captured sampler loop ---------------------------------- */
 int od_graph_begin(void* stream);
 int od_graph_end(void* stream, void** graph_exec_out);

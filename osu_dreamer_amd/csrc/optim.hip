@@ -48,7 +48,23 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
     }
 }
 
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float decay, int mode) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float pi = p[i];
+        if (mode == 1) ema[i] = pi;
+        else { const float e = ema[i]; ema[i] = e + (1.f - decay) * (pi - e); }
+    }
+}
+
 }  // namespace
+
+extern "C" int od_ema_update(float* ema, const float* p, long n, float ema_decay, int ema_mode, void* stream) {
+    if (n <= 0 || (ema_mode != 1 && ema_mode != 2)) return OD_ERR_ARG;
+    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+    OD_LAUNCH(ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ema, p, n, ema_decay, ema_mode);
+    OD_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int od_sqnorm(const float* g, long n, float* out, void* stream) {
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;

@@ -1,0 +1,322 @@
+"""Launch plan for the denoiser: the explicit forward / backward kernel sequence over
+pre-allocated frame-major workspaces.
+
+This is the host-side replacement of the reference's module graph
+(osu_dreamer/models/diffusion/model.py:86-103 `_pred`, backbone.py:69-88
+`BackboneLayer.forward`, common/attn.py:74-84, common/swiglu.py:27-32) and of the autograd
+tape torch would record for it.  Every arithmetic step is an `od_*` HIP kernel
+(osu_dreamer_amd/ops.py); torch tensors are storage only.  Nothing is allocated inside
+`pred` / `forward_train` / `backward`, so a sampler step is hipGraph-capturable.
+
+Layout: activations are [M = B*L, C] frame-major (csrc/od_common.h).  The SwiGLU hidden
+width Hf = int(D*expand*2/3) (1365 at default hparams, odd) is padded to Hp = ceil64(Hf):
+packed vg weights put v at rows [0,Hf) and g at rows [Hp,Hp+Hf) with zero rows between,
+so every kernel sees aligned, zero-padded columns.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from ._lib import OD_ACT_NONE, OD_ACT_SILU
+
+FP32_EPS = float(torch.finfo(torch.float32).eps)   # nn.RMSNorm(eps=None), common/attn.py:71-72
+
+
+def _ceil(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Workspace:
+    """Named device buffers, allocated once per plan."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t: Dict[str, torch.Tensor] = {}
+        self.bytes = 0
+
+    def get(self, name: str, shape, dtype) -> torch.Tensor:
+        t = self.t.get(name)
+        if t is None:
+            t = torch.zeros(shape, dtype=dtype, device=self.device)
+            self.t[name] = t
+            self.bytes += t.numel() * t.element_size()
+        return t
+
+
+class DenoiserEngine:
+    def __init__(self, model):
+        self.model = model
+        a = model.args
+        ba = a.backbone_args
+        self.E, self.A, self.S = model.emb_dim, model.a_dim, model.style_dim
+        self.Cg, self.D, self.U = a.global_cond_dim, a.backbone_dim, a.u_head_dim
+        self.H, self.hd, self.depth = ba.n_heads, ba.head_dim, ba.depth
+        self.dh = self.H * self.hd
+        self.radius = ba.radius
+        self.ksize = 1 + 2 * ba.radius
+        self.Hf = int(self.D * ba.expand * 2 / 3)
+        self.Hp = _ceil(self.Hf, 64)
+        if ba.radius not in (1, 2):
+            raise NotImplementedError("depthwise kernel sizes 3 and 5 (radius 1, 2) are compiled")
+        if ba.dropout != 0.0:
+            raise NotImplementedError("Dropout1d with p > 0 is not on the compiled path (model.yml uses 0)")
+        self._packed: Dict[str, torch.Tensor] = {}
+        self._packed_key = None
+        self._plan_key = None
+        self.ws: Optional[Workspace] = None
+        self._rowmap = None
+
+    # ------------------------------------------------------------------ parameters
+    def P(self, name: str) -> torch.Tensor:
+        return self.model.arena.view(name)
+
+    def G(self, name: str) -> torch.Tensor:
+        return self.model.arena.grad_view(name)
+
+    def _gemm_weights(self) -> List[str]:
+        names = ["proj_audio.0"]
+        for i in range(self.depth):
+            p = f"net.layers.{i}."
+            names += [p + "proj_cl", p + "attn.qkv_proj", p + "attn.out_proj", p + "ffn.proj_vg.1", p + "ffn.proj_o"]
+        return names
+
+    def pack_weights(self, dtype: torch.dtype, train: bool):
+        """fp32 masters -> compute-dtype GEMM operands (and their transposes for backward-data)."""
+        dev = self.model.arena.data.device
+        key = (dtype, train, dev)
+        if self._packed_key != key:
+            self._packed = {}
+            self._packed_key = key
+            Hf, Hp = self.Hf, self.Hp
+            rm = [-1] * (2 * Hp)
+            for j in range(Hf):
+                rm[j] = j
+                rm[Hp + j] = Hf + j
+            self._rowmap = torch.tensor(rm, dtype=torch.int32, device=dev)
+        pk = self._packed
+        for n in self._gemm_weights():
+            w = self.P(n + ".weight")
+            N, K = w.shape[0], w.shape[1]
+            Np, Kp, rmap = N, K, None
+            if n.endswith("ffn.proj_vg.1"):
+                Np, rmap = 2 * self.Hp, self._rowmap
+            if n.endswith("ffn.proj_o"):
+                Kp = self.Hp
+            if n not in pk:
+                pk[n] = torch.empty(Np, Kp, dtype=dtype, device=dev)
+                if train:
+                    pk[n + ".T"] = torch.empty(Kp, Np, dtype=dtype, device=dev)
+                if rmap is not None:
+                    pk[n + ".b"] = torch.empty(Np, dtype=torch.float32, device=dev)
+            ops.pack_weight(w, pk[n], row_map=rmap)
+            if train:
+                ops.pack_weight(w, pk[n + ".T"], transpose=True, row_map=rmap)
+            if rmap is not None:
+                ops.pack_weight(self.P(n + ".bias"), pk[n + ".b"].view(Np, 1), row_map=rmap)
+
+    def W(self, name: str, T: bool = False) -> torch.Tensor:
+        return self._packed[name + (".T" if T else "")]
+
+    # ------------------------------------------------------------------ plan / workspace
+    def plan(self, B: int, L: int, Ba: int, dtype: torch.dtype, train: bool):
+        dev = self.model.arena.data.device
+        key = (B, L, Ba, dtype, train, dev)
+        if key != self._plan_key:
+            self.ws = Workspace(dev)
+            self._plan_key = key
+            tab = self.ws.get("rope", (L, self.hd // 2, 2), torch.float32)
+            ops.rope_table(tab, L, self.hd)
+        self.B, self.L, self.Ba, self.dtype, self.train = B, L, Ba, dtype, train
+        self.M, self.Ma = B * L, Ba * L
+        return self.ws
+
+    def buf(self, name, shape, dtype=None):
+        return self.ws.get(name, shape, self.dtype if dtype is None else dtype)
+
+    def lbuf(self, name, i, shape, dtype=None):
+        """Per-layer buffer when training (saved for backward), shared scratch otherwise."""
+        return self.buf(f"{name}.{i}" if self.train else name, shape, dtype)
+
+    # ------------------------------------------------------------------ conditioning (model.py:73-84)
+    def conditioning(self, audio: torch.Tensor, style: torch.Tensor):
+        """proj_audio, proj_style and everything that depends only on (audio, style):
+        ssg1/ssg2 of every layer, u_mod, and (inference) every layer's proj_cl(a) — the
+        loop invariants the reference recomputes on each of the sampler's evaluations."""
+        B, Ba, L = self.B, self.Ba, self.L
+        D, A, Cg, U = self.D, self.A, self.Cg, self.U
+        f32 = torch.float32
+        a_t = self.buf("a_t", (self.Ma, A))
+        a_pre = self.buf("a_pre", (self.Ma, A))
+        a = self.buf("a", (self.Ma, A))
+        ops.cl_to_frames(audio, a_t)
+        ops.gemm_nt(a_t, self.W("proj_audio.0"), self.P("proj_audio.0.bias"), a_pre)
+        ops.silu(a_pre, a)
+        cg, cg_pre = self.buf("cg", (B, Cg), f32), self.buf("cg_pre", (B, Cg), f32)
+        ops.linear_small(style, self.P("proj_style.0.weight"), self.P("proj_style.0.bias"), cg, cg_pre, OD_ACT_SILU)
+        for i in range(self.depth):
+            p = f"net.layers.{i}."
+            for s in ("ssg1", "ssg2"):
+                ops.linear_small(cg, self.P(p + s + ".weight"), self.P(p + s + ".bias"),
+                                 self.buf(f"{s}.{i}", (B, 3 * D), f32))
+            if not self.train:
+                ops.gemm_nt(a, self.W(p + "proj_cl"), self.P(p + "proj_cl.bias"), self.buf(f"cl.{i}", (self.Ma, D)))
+        ops.linear_small(cg, self.P("u_mod.weight"), self.P("u_mod.bias"), self.buf("umod", (B, 2 * U), f32))
+
+    # ------------------------------------------------------------------ forward (model.py:86-103)
+    def pred(self, xt: torch.Tensor, u: torch.Tensor, v: torch.Tensor):
+        B, L, M, D, dh, Hp = self.B, self.L, self.M, self.D, self.dh, self.Hp
+        f32 = torch.float32
+        tab = self.ws.t["rope"]
+        bcast = self.Ba == 1 and B > 1
+        x = self.lbuf("x_in", 0, (M, D))
+        ops.proj_in(xt, self.P("proj_in.weight"), self.P("proj_in.bias"), x)
+        for i in range(self.depth):
+            p = f"net.layers.{i}."
+            ssg1, ssg2 = self.ws.t[f"ssg1.{i}"], self.ws.t[f"ssg2.{i}"]
+            if self.train:
+                cl = self.buf("cl", (self.Ma, D))
+                ops.gemm_nt(self.ws.t["a"], self.W(p + "proj_cl"), self.P(p + "proj_cl.bias"), cl)
+            else:
+                cl = self.ws.t[f"cl.{i}"]
+            # --- attention branch (backbone.py:76-80, attn.py:74-84)
+            h1 = self.lbuf("h1", i, (M, D))
+            ops.rmsnorm_film(x, ssg1, cl, bcast, h1, self.lbuf("inv1", i, (M,), f32), B, L)
+            qkv = self.lbuf("qkv", i, (M, 3 * dh))
+            ops.gemm_nt(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv)
+            qk = self.lbuf("qk", i, (M, 2 * dh))
+            ops.qk_norm_rope(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, qk,
+                             B, L, self.H, self.hd, FP32_EPS)
+            y = self.lbuf("y", i, (M, dh))
+            lse = self.lbuf("lse", i, (B, self.H, L), f32)
+            ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, self.H, L, self.hd,
+                               1.0 / math.sqrt(self.hd))
+            ao = self.lbuf("ao", i, (M, D))
+            ops.gemm_nt(y, self.W(p + "attn.out_proj"), self.P(p + "attn.out_proj.bias"), ao)
+            x_mid = self.lbuf("x_mid", i, (M, D))
+            ops.rmsnorm_gate_residual(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), B, L)
+            # --- feed-forward branch (backbone.py:82-86, swiglu.py:27-32)
+            h2 = self.lbuf("h2", i, (M, D))
+            ops.rmsnorm_film(x_mid, ssg2, None, False, h2, self.lbuf("inv3", i, (M,), f32), B, L)
+            hdw = self.lbuf("hdw", i, (M, D))
+            ops.dwconv(h2, self.P(p + "ffn.proj_vg.0.weight"), self.P(p + "ffn.proj_vg.0.bias"), hdw, B, L, self.ksize)
+            vg = self.lbuf("vg", i, (M, 2 * Hp))
+            ops.gemm_nt(hdw, self.W(p + "ffn.proj_vg.1"), self._packed[p + "ffn.proj_vg.1.b"], vg)
+            hh = self.lbuf("hh", i, (M, Hp))
+            ops.swiglu_rmsnorm(vg, hh, self.lbuf("inv4", i, (M,), f32), self.Hf, Hp)
+            fo = self.lbuf("fo", i, (M, D))
+            ops.gemm_nt(hh, self.W(p + "ffn.proj_o"), self.P(p + "ffn.proj_o.bias"), fo)
+            # next layer input; at inference x_in.0 / x_in.1 ping-pong
+            x = self.buf(f"x_in.{i + 1}", (M, D)) if self.train else self.buf(f"x_in.{(i + 1) & 1}", (M, D))
+            ops.rmsnorm_gate_residual(x_mid, fo, ssg2, x, self.lbuf("inv5", i, (M,), f32), B, L)
+        self._x_last = x
+        ops.final_norm_proj_out(x, self.P("proj_out.weight"), self.P("proj_out.bias"), v,
+                                self.buf("invf", (M,), f32), B, L)
+        # distance head on the raw latent (model.py:99-102)
+        fsum = self.buf("fsum", (B, self.U), f32)
+        fsum.zero_()
+        ops.uhead_fwd(xt, self._uhead_w(), fsum, self.U)
+        ops.uhead_tail(fsum, self.ws.t["umod"], self.P("u_out.weight"), self.P("u_out.bias"), u, L, self.model.u_scale)
+
+    def _uhead_w(self, grads=False):
+        f = self.G if grads else self.P
+        return [f(f"u_head.{j}.{s}") for j in (0, 1, 3, 4) for s in ("weight", "bias")]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, xt: torch.Tensor, style: torch.Tensor, du: torch.Tensor, dv: torch.Tensor, reducer=None):
+        """Accumulate dLoss/dparam into the arena's grad buffer given dLoss/du [B], dLoss/dv (B,E,L).
+        Mirrors `pred` in reverse.  `reducer.layer_done(i)` (if given) is told when a layer's
+        gradients are final so their all-reduce can overlap the rest of backward."""
+        assert self.train
+        B, L, M, D, dh, Hf, Hp, A = self.B, self.L, self.M, self.D, self.dh, self.Hf, self.Hp, self.A
+        f32 = torch.float32
+        tab = self.ws.t["rope"]
+        cg, a = self.ws.t["cg"], self.ws.t["a"]
+        # residual-stream gradient and scratch
+        dx = self.buf("d.x", (M, D))
+        dbr = self.buf("d.branch", (M, D))
+        dtmp = self.buf("d.tmp", (M, D))
+        dhh = self.buf("d.hh", (M, Hp))
+        dvg = self.buf("d.vg", (M, 2 * Hp))
+        dy = self.buf("d.y", (M, dh))
+        dqk = self.buf("d.qk", (M, 2 * dh))
+        dqkv = self.buf("d.qkv", (M, 3 * dh))
+        da = self.buf("d.a", (self.Ma, A))
+        delta = self.buf("d.delta", (B, self.H, L), f32)
+        dcg = self.buf("d.cg", (B, self.Cg), f32)
+        dssg1, dssg2 = self.buf("d.ssg1", (B, 3 * D), f32), self.buf("d.ssg2", (B, 3 * D), f32)
+
+        ops.final_norm_proj_out_bwd(self._x_last, self.ws.t["invf"], self.P("proj_out.weight"), dv, dx,
+                                    self.G("proj_out.weight"), self.G("proj_out.bias"), B, L)
+        # distance head
+        dfm, dmod = self.buf("d.fm", (B, self.U), f32), self.buf("d.mod", (B, 2 * self.U), f32)
+        ops.uhead_tail_bwd(self.ws.t["fsum"], self.ws.t["umod"], self.P("u_out.weight"), self.P("u_out.bias"), du,
+                           dfm, dmod, self.G("u_out.weight"), self.G("u_out.bias"), L, self.model.u_scale)
+        ops.uhead_bwd(xt, self._uhead_w(), dfm, self._uhead_w(grads=True), self.U)
+        ops.linear_small_bwd(cg, self.P("u_mod.weight"), None, dmod, self.buf("d.lin_pre_umod", (B, 2 * self.U), f32),
+                             self.G("u_mod.weight"), self.G("u_mod.bias"), dcg, False, OD_ACT_NONE)
+        if reducer is not None:
+            reducer.segment_done("tail")
+
+        for i in reversed(range(self.depth)):
+            p = f"net.layers.{i}."
+            t = self.ws.t
+            ssg1, ssg2 = t[f"ssg1.{i}"], t[f"ssg2.{i}"]
+            dssg1.zero_()
+            dssg2.zero_()
+            # ---- feed-forward branch
+            ops.rmsnorm_gate_residual_bwd(t[f"fo.{i}"], t[f"inv5.{i}"], ssg2, dx, dbr, dssg2, B, L)
+            ops.gemm_tn(dbr, t[f"hh.{i}"], self.G(p + "ffn.proj_o.weight"), n_cols=D, k_cols=Hf)
+            ops.colsum(dbr, self.G(p + "ffn.proj_o.bias"))
+            ops.gemm_nt(dbr, self.W(p + "ffn.proj_o", T=True), None, dhh)
+            ops.swiglu_rmsnorm_bwd(t[f"vg.{i}"], t[f"inv4.{i}"], dhh, dvg, Hf, Hp)
+            gw, gb = self.G(p + "ffn.proj_vg.1.weight"), self.G(p + "ffn.proj_vg.1.bias")
+            hdw = t[f"hdw.{i}"]
+            ops.gemm_tn(dvg[:, :Hp], hdw, gw[:Hf], n_cols=Hf, k_cols=D)
+            ops.gemm_tn(dvg[:, Hp:], hdw, gw[Hf:], n_cols=Hf, k_cols=D)
+            ops.colsum(dvg[:, :Hp], gb[:Hf], n_cols=Hf)
+            ops.colsum(dvg[:, Hp:], gb[Hf:], n_cols=Hf)
+            ops.gemm_nt(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dtmp)
+            ops.dwconv_bwd(t[f"h2.{i}"], self.P(p + "ffn.proj_vg.0.weight"), dtmp, dbr,
+                           self.G(p + "ffn.proj_vg.0.weight"), self.G(p + "ffn.proj_vg.0.bias"), B, L, self.ksize)
+            ops.rmsnorm_film_bwd(t[f"x_mid.{i}"], t[f"inv3.{i}"], ssg2, dbr, dx, dssg2, B, L)
+            # ---- attention branch
+            ops.rmsnorm_gate_residual_bwd(t[f"ao.{i}"], t[f"inv2.{i}"], ssg1, dx, dbr, dssg1, B, L)
+            ops.gemm_tn(dbr, t[f"y.{i}"], self.G(p + "attn.out_proj.weight"))
+            ops.colsum(dbr, self.G(p + "attn.out_proj.bias"))
+            ops.gemm_nt(dbr, self.W(p + "attn.out_proj", T=True), None, dy)
+            qk, qkv = t[f"qk.{i}"], t[f"qkv.{i}"]
+            ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], t[f"y.{i}"], dy, t[f"lse.{i}"], delta,
+                               dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:], B, self.H, L, self.hd, 1.0 / math.sqrt(self.hd))
+            ops.qk_norm_rope_bwd(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, dqk, dqkv,
+                                 self.G(p + "attn.q_norm.weight"), self.G(p + "attn.k_norm.weight"), B, L, self.H,
+                                 self.hd, FP32_EPS)
+            ops.gemm_tn(dqkv, t[f"h1.{i}"], self.G(p + "attn.qkv_proj.weight"))
+            ops.colsum(dqkv, self.G(p + "attn.qkv_proj.bias"))
+            ops.gemm_nt(dqkv, self.W(p + "attn.qkv_proj", T=True), None, dtmp)      # d h1 (== d cl)
+            ops.gemm_tn(dtmp, a, self.G(p + "proj_cl.weight"))
+            ops.colsum(dtmp, self.G(p + "proj_cl.bias"))
+            ops.gemm_nt(dtmp, self.W(p + "proj_cl", T=True), None, da, accumulate=(i != self.depth - 1))
+            ops.rmsnorm_film_bwd(t[f"x_in.{i}"], t[f"inv1.{i}"], ssg1, dtmp, dx, dssg1, B, L)
+            # ---- the two modulation linears of this layer
+            lp = self.buf("d.lin_pre_ssg", (B, 3 * D), f32)
+            ops.linear_small_bwd(cg, self.P(p + "ssg2.weight"), None, dssg2, lp, self.G(p + "ssg2.weight"),
+                                 self.G(p + "ssg2.bias"), dcg, True, OD_ACT_NONE)
+            ops.linear_small_bwd(cg, self.P(p + "ssg1.weight"), None, dssg1, lp, self.G(p + "ssg1.weight"),
+                                 self.G(p + "ssg1.bias"), dcg, True, OD_ACT_NONE)
+            if reducer is not None:
+                reducer.segment_done(f"layer{i}")
+
+        ops.proj_in_bwd(xt, dx, self.G("proj_in.weight"), self.G("proj_in.bias"))
+        da_pre = self.buf("d.a_pre", (self.Ma, A))
+        ops.silu_bwd(self.ws.t["a_pre"], da, da_pre)
+        ops.gemm_tn(da_pre, self.ws.t["a_t"], self.G("proj_audio.0.weight"))
+        ops.colsum(da_pre, self.G("proj_audio.0.bias"))
+        ops.linear_small_bwd(style, self.P("proj_style.0.weight"), self.ws.t["cg_pre"], dcg,
+                             self.buf("d.lin_pre_style", (B, self.Cg), f32), self.G("proj_style.0.weight"),
+                             self.G("proj_style.0.bias"), None, False, OD_ACT_SILU)
+        if reducer is not None:
+            reducer.segment_done("head")

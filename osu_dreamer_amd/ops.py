@@ -296,3 +296,8 @@ def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, weight_decay, step, ema_de
     _f32(p, g, m, v, ema, gnorm_sq)
     _lib.lib().od_adamw_ema(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                             ema_decay, ema_mode, _p(gnorm_sq), max_norm, _stream(p))
+
+
+def ema_update(ema, p, decay, mode):
+    _f32(ema, p)
+    _lib.lib().od_ema_update(_p(ema), _p(p), p.numel(), decay, mode, _stream(p))

@@ -1,0 +1,152 @@
+"""End-to-end parity of the HIP path (DiffusionModel / DiffusionTrainer / FusedAdamWEMA)
+against the golden fixtures the REFERENCE produced (tests/golden, see oracle/make_golden.py).
+
+Tolerances (fp32 compute): forward v 5e-5 rel-L2, u 1e-5; sampler 1e-4 rel-L2 (north_star);
+parameter gradients 1e-3 rel-L2 per tensor; two optimizer+EMA steps allclose(rtol 1e-4).
+bf16 compute: forward error vs the fp32 reference must stay within 3x the error the reference's
+own bf16-autocast run shows on the same inputs (recorded in the fixture).
+Tiny configs run on the emulator build (CPU) and on the GPU; full-width configs on the GPU only.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser_oracle as O
+from osu_dreamer_amd.model import BackboneArgs, DiffusionModel, DiffusionModelArgs
+from osu_dreamer_amd.train import DiffusionTrainer
+from osu_dreamer_amd.lr_schedule import LRScheduleArgs
+from kernel_backend import dev, rel_l2  # noqa: F401
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def dims_of(fx):
+    keys = list(O.Dims().to_dict().keys())
+    return O.Dims(**{k: int(v) for k, v in zip(keys, fx["dims"].tolist())})
+
+
+def margs(d):
+    return DiffusionModelArgs(d.global_cond_dim, d.backbone_dim,
+                              BackboneArgs(d.depth, d.expand, d.head_dim, d.n_heads, d.radius), d.u_head_dim)
+
+
+def inputs(fx, d):
+    if "in.h" in fx:
+        return ({k[2:]: v for k, v in fx.items() if k.startswith("w.")},
+                {k[3:]: v for k, v in fx.items() if k.startswith("in.")})
+    seed = int(fx["seed"])
+    return O.init_params(d, seed=seed), O.synthetic_batch(d, int(fx["B"]), int(fx["L"]), seed=seed + 1)
+
+
+def make_trainer(d, P, device):
+    tr = DiffusionTrainer(val_batches=2, opt_args=dict(lr=3e-4, weight_decay=0.01),
+                          schedule_args=LRScheduleArgs(warmup_init=.3, warmup_steps=1000, decay_start=30000),
+                          osl_weight=1., del_weight=30., emb_dim=d.emb_dim, a_dim=d.a_dim, style_dim=d.style_dim,
+                          diffusion_args=margs(d))
+    assert list(tr.diffusion.state_dict().keys()) == list(P.keys())
+    tr.diffusion.load_state_dict(P)
+    tr.diffusion_ema.module.load_state_dict(P)
+    return tr.to(device)
+
+
+CASES = [
+    pytest.param("tiny_b3_l40", id="tiny_b3_l40"),
+    pytest.param("tiny_b2_l77_bcast", id="tiny_b2_l77_bcast"),
+]
+GPU_ONLY = [
+    pytest.param("full_d2_b2_l96", id="full_d2_b2_l96"),
+    pytest.param("full_d8_b2_l64", id="full_d8_b2_l64"),
+]
+
+
+def run_case(name, dev):
+    fx = load(name)
+    d = dims_of(fx)
+    P, data = inputs(fx, d)
+    tr = make_trainer(d, P, dev)
+    model = tr.diffusion
+    dd = {k: v.to(dev) for k, v in data.items()}
+    xt = torch.lerp(data["x0"], data["z"], data["t"][:, None, None]).to(dev)
+
+    # ---- forward (no grad)
+    with torch.no_grad():
+        u, v = model(dd["h"], dd["s"], xt)
+    assert rel_l2(u, fx["fwd_u"]) < 1e-5
+    assert rel_l2(v, fx["fwd_v"]) < 5e-5
+
+    # ---- bf16 compute, anchored to the reference's own bf16 error
+    if "fwd_v_bf16" in fx:
+        model.compute_dtype = torch.bfloat16
+        with torch.no_grad():
+            ub, vb = model(dd["h"], dd["s"], xt)
+        model.compute_dtype = None
+        ref_err = rel_l2(fx["fwd_v_bf16"], fx["fwd_v"])
+        assert rel_l2(vb, fx["fwd_v"]) < 3 * ref_err + 1e-3, (rel_l2(vb, fx["fwd_v"]), ref_err)
+        assert rel_l2(ub, fx["fwd_u"]) < 2e-2
+
+    # ---- sampler
+    xs = model.sample(dd["h"], dd["s"], int(fx["num_steps"]), x_init=dd["x_init"])
+    assert rel_l2(xs, fx["sample_x"]) < 1e-4
+
+    # ---- training loss + gradients through the trainer's forward
+    opt_cfg = tr.configure_optimizers()
+    opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+    opt.max_grad_norm = 1.0
+    opt.zero_grad()
+    loss, logs = tr(model, dd["h"], dd["z"], dd["s"], None, t=fx["t_used"].to(dev), x0=dd["x0"])
+    assert float(loss) == pytest.approx(float(fx["loss"]), rel=5e-5)
+    for k in ("osl", "del", "u_mape"):
+        assert float(logs[k]) == pytest.approx(float(fx["log_" + k]), rel=1e-4)
+    loss.backward()
+    gn = float(model.arena.grad.double().norm())
+    assert gn == pytest.approx(float(fx["grad_norm"]), rel=2e-4)
+    worst = 0.0
+    for k, p in model.named_parameters():
+        g = p.grad.cpu()
+        if "grad." + k in fx:
+            e = rel_l2(g, fx["grad." + k])
+            assert e < 1e-3, (k, e)
+            worst = max(worst, e)
+        else:
+            assert float(g.norm()) == pytest.approx(float(fx["gradnorm." + k]), rel=3e-3, abs=1e-6), k
+            n = g.numel()
+            assert torch.allclose(g.flatten()[::max(1, n // 64)][:64], fx["gradsub." + k], rtol=2e-2, atol=2e-5 * float(fx["gradnorm." + k]) + 1e-7), k
+
+    # ---- two optimizer + EMA steps on those gradients (clip 1.0, lr schedule steps 0 and 1)
+    for _ in range(2):
+        opt.step()
+        sched.step()
+        tr.on_train_batch_end()
+    assert int(tr.diffusion_ema.n_averaged) == int(fx["n_averaged"])
+    assert opt.param_groups[0]["lr"] == pytest.approx(float(fx["lr_after"][0]), rel=1e-9)
+    ema = tr.diffusion_ema.module
+    for (k, p), (_, e) in zip(model.named_parameters(), ema.named_parameters()):
+        if "p2." + k in fx:
+            assert torch.allclose(p.detach().cpu(), fx["p2." + k], rtol=1e-4, atol=3e-6), k
+            assert torch.allclose(e.detach().cpu(), fx["ema2." + k], rtol=1e-4, atol=3e-6), k
+        else:
+            n = p.numel()
+            assert torch.allclose(p.detach().cpu().flatten()[::max(1, n // 64)][:64], fx["p2sub." + k], rtol=1e-4, atol=3e-6), k
+            assert torch.allclose(e.detach().cpu().flatten()[::max(1, n // 64)][:64], fx["ema2sub." + k], rtol=1e-4, atol=3e-6), k
+    return worst
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_tiny_vs_reference(dev, name):
+    run_case(name, dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GPU_ONLY)
+def test_full_width_vs_reference(name):
+    from osu_dreamer_amd import _lib
+    _lib._lib = None
+    _lib.lib()
+    run_case(name, torch.device("cuda:0"))
