@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Benchmark of the denoiser hot path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Step = one training step of BASELINE.json configs[1] per GPU: batch 32 x 8192-frame synthetic
+latents, bf16 compute — noise draw, xt, denoiser forward, distance-marching loss, full backward,
+(N>1: RCCL all-reduce of the 46.9 M fp32 gradients, overlapped), global-norm clip, AdamW, EMA.
+Weak scaling: every rank runs its own batch of 32; `value` = rank-steps per second over the job.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def default_model_args():
+    from osu_dreamer_amd.model import BackboneArgs, DiffusionModelArgs
+    # osu_dreamer/models/diffusion/model.yml:62-91
+    return dict(emb_dim=6, a_dim=128, style_dim=32,
+                diffusion_args=DiffusionModelArgs(global_cond_dim=512, backbone_dim=512, u_head_dim=64,
+                                                  backbone_args=BackboneArgs(head_dim=64, n_heads=16, depth=8, expand=4, radius=2)))
+
+
+def make_trainer(device, seed):
+    from osu_dreamer_amd.lr_schedule import LRScheduleArgs
+    from osu_dreamer_amd.train import DiffusionTrainer
+    torch.manual_seed(seed)
+    tr = DiffusionTrainer(val_batches=8, opt_args=dict(lr=3e-4, weight_decay=0.01),
+                          schedule_args=LRScheduleArgs(warmup_init=.3, warmup_steps=1000, decay_start=30000),
+                          osl_weight=1., del_weight=30., **default_model_args())
+    # zero-initialised tensors (ssg/proj_out/u_mod) would make every layer the identity and all
+    # gradients trivially sparse: give them N(0, 0.02) so the step does representative work.
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in tr.diffusion.named_parameters():
+            if any(z in n for z in ("ssg1.", "ssg2.", "proj_out.", "u_mod.")) or n == "u_out.weight":
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    tr.diffusion_ema.module.load_state_dict(tr.diffusion.state_dict())
+    tr.gradient_clip_val = 1.0
+    return tr.to(device)
+
+
+def synthetic_batch(B, L, device, seed):
+    """h ~ N(0,1); z per-frame RMS-normalised N(0,1); s RMS-normalised N(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    h = torch.randn(B, 128, L, generator=g)
+    z = torch.randn(B, 6, L, generator=g)
+    z = z * torch.rsqrt((z * z).mean(1, keepdim=True) + 1e-6)
+    s = torch.randn(B, 32, generator=g)
+    s = s * torch.rsqrt((s * s).mean(1, keepdim=True) + 1e-6)
+    labels = torch.rand(B, 5, generator=g) * 10
+    return tuple(t.to(device) for t in (h, z, s, labels))
+
+
+def flops_forward(frames, L):
+    """Algorithmic forward FLOPs (SURVEY.md §8d closed form, verified against FlopCounterMode)."""
+    return frames * (68_244_644 + 32_768 * L)
+
+
+def time_kernel(fn, iters=3):
+    """Average duration (s) of `fn` on torch's current stream, measured with HIP events."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def roofline_of_dominant_kernel(tr, B, L):
+    """Re-launch the step's dominant kernel (flash-attention backward dK/dV, 4 of the 9 attention
+    MFMA passes per layer) alone on the step's own buffers and time it with HIP events."""
+    from osu_dreamer_amd import ops
+    eng = tr.diffusion.engine
+    t = eng.ws.t
+    H, hd, dh = eng.H, eng.hd, eng.dh
+    i = eng.depth - 1
+    qk, qkv, y, lse = t[f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
+    dy, dqk, dqkv, delta = t["d.y"], t["d.qk"], t["d.qkv"], t["d.delta"]
+    scale = 1 / math.sqrt(hd)
+
+    def bwd():
+        ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
+                           dqkv[:, 2 * dh:], B, H, L, hd, scale)
+
+    def fwd():
+        ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, H, L, hd, scale)
+    unit = 2.0 * B * H * L * L * hd                 # one L x L x hd MFMA pass over all heads
+    t_bwd, t_fwd = time_kernel(bwd), time_kernel(fwd)
+    # od_flash_attn_bwd = delta + dK/dV kernel (4 passes) + dQ kernel (3 passes); fwd = 2 passes
+    ach_bwd = 7 * unit / t_bwd / 1e12
+    ach_fwd = 2 * unit / t_fwd / 1e12
+    return {
+        "bound": "mfma", "kernel": "flash_bwd_dkv_kernel+flash_bwd_dq_kernel (od_flash_attn_bwd)",
+        "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        "ms_per_launch": round(t_bwd * 1e3, 3),
+        "also": {"od_flash_attn_fwd": {"achieved": round(ach_fwd, 1), "frac": round(ach_fwd / PEAK_BF16_TFLOPS, 4),
+                                       "ms_per_launch": round(t_fwd * 1e3, 3)}},
+    }
+
+
+def cpu_baseline(L_cpu=1024):
+    """The CPU oracle (a port of the reference path, pinned by tests/golden) timed on this box's
+    host cores on a bounded sample: ONE fp32 training step at batch 1 x L_cpu frames, scaled to the
+    metric's unit by frames (a bench step is 32 x 8192 frames)."""
+    from oracle import denoiser_oracle as O
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    d = O.FULL
+    P = O.init_params(d, seed=7)
+    data = O.synthetic_batch(d, 1, L_cpu, seed=8)
+    m = {k: torch.zeros_like(v) for k, v in P.items()}
+    vv = {k: torch.zeros_like(v) for k, v in P.items()}
+    ema = {k: v.clone() for k, v in P.items()}
+    t0 = time.time()
+    _, _, grads = O.loss_and_grads(P, d, data["h"], data["z"], data["s"], data["t"], data["x0"])
+    _, coef = O.clip_coef(grads, 1.0)
+    O.adamw_ema_step(P, grads, m, vv, ema, 1, 3e-4, clip=coef, first_ema=True)
+    dt = time.time() - t0
+    frames_per_s = L_cpu / dt
+    return {"value": frames_per_s / (32 * 8192), "unit": "train-steps/s (32x8192-frame step equivalent)",
+            "cores": cores, "kind": "port",
+            "sample": f"1 fp32 train step, batch 1 x {L_cpu} frames, {dt:.1f} s, {frames_per_s:.0f} frames/s; "
+                      f"attention cost grows with L, so this over-states the CPU rate at L=8192"}
+
+
+def sampler_bench(device):
+    """BASELINE configs[3]: 50-step sampler, 4 diffs in parallel on a 3-min song (L=1115 latent frames),
+    fp32 compute (the 1e-4 parity mode), hipGraph-captured step."""
+    from osu_dreamer_amd.model import DiffusionModel
+    a = default_model_args()
+    torch.manual_seed(5)
+    m = DiffusionModel(a["emb_dim"], a["a_dim"], a["style_dim"], a["diffusion_args"])
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if any(z in n for z in ("ssg1.", "ssg2.", "proj_out.", "u_mod.")) or n == "u_out.weight":
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    m = m.to(device)
+    B, L = 4, 1115
+    h = torch.randn(1, 128, L, generator=g).to(device)
+    s = torch.randn(B, 32, generator=g).to(device)
+    out = {}
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m.compute_dtype = dt
+        m.sample(h, s, 50)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        m.sample(h, s, 50)
+        torch.cuda.synchronize()
+        dt_s = time.time() - t0
+        out[name] = {"latents_per_s": round(B * L / dt_s, 1), "ms_per_sample_call": round(dt_s * 1e3, 2),
+                     "tflops": round(51 * flops_forward(B * L, L) / dt_s / 1e12, 1)}
+    return {"workload": "50-step sampler, B=4, L=1115, audio batch 1 (broadcast), hipGraph", **out}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=8192)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / sampler legs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    from osu_dreamer_amd import _lib
+    _lib.lib()                                   # fail loudly if the HIP library is missing
+    reducer = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    B, L = args.batch, args.frames
+    tr = make_trainer(device, seed=1234)
+    tr.diffusion.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if world > 1:
+        from osu_dreamer_amd.ddp import GradBucketReducer
+        reducer = GradBucketReducer(tr.diffusion)
+        reducer.broadcast_parameters(0)
+    batch = synthetic_batch(B, L, device, seed=1234 + rank)
+    cfg = tr.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+
+    def step(i):
+        opt.zero_grad()
+        loss = tr.training_step(batch, i)
+        loss.backward()
+        opt.step()
+        sched.step()
+        tr.on_train_batch_end()
+        return loss
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss = step(i)
+    barrier()
+    t0 = time.time()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    final_loss = float(loss.detach())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        frames = B * L
+        f_fwd = flops_forward(frames, L)
+        # executed MFMA work: forward + 2x GEMM backward + attention backward as 7 passes (vs 2 forward)
+        attn_fwd = frames * 32_768 * L
+        executed = f_fwd + 2 * (f_fwd - attn_fwd) + 3.5 * attn_fwd
+        line = {
+            "metric": "denoiser train-steps/sec + 50-step sample latents/sec, 1/2/4/8 MI355X",
+            "value": round(world * args.steps / dt, 4), "unit": "train-steps/s (rank-steps of batch 32 x 8192 frames)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"single-GPU denoiser training, batch={B}, {L}-frame synthetic latents, {args.dtype} "
+                                   "(BASELINE.json configs[1]); per-rank batch fixed under --gpus N",
+                       "per_gpu_batch": B, "global_batch": B * world, "frames": L, "params": 46_877_103,
+                       "parallelism": f"dp{world}"},
+            "frames_per_s": round(world * frames * args.steps / dt, 1),
+            "algorithmic_tflops_per_step": round(3 * f_fwd / 1e12, 1),
+            "achieved_tflops_algorithmic": round(3 * f_fwd / (dt / args.steps) / 1e12, 1),
+            "achieved_tflops_executed": round(executed / (dt / args.steps) / 1e12, 1),
+            "mfma_frac_whole_step": round(3 * f_fwd / (dt / args.steps) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 4),
+            "final_loss": round(final_loss, 4),
+            "workspace_gb": round(tr.diffusion.engine.ws.bytes / 2**30, 1),
+        }
+        if not args.no_extras and world == 1:
+            line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
+            line["sampler"] = sampler_bench(device)
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
