@@ -56,6 +56,22 @@ __device__ __forceinline__ void frag_perm(od_frag<float>& f, const unsigned char
     f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
 }
 
+// "column" fragment: element j of lane (x, g) = tile[row 32u + 16*(j>>2) + 4g + (j&3)][col c0 + x].
+// bf16: two LDS transpose reads (ds_read_b64_tr_b16) from the ROW-MAJOR tile — no transposed copy
+// of the tile exists.  f32: two 16-byte reads from a transposed tile written at staging time.
+template <int ROWB, int TROWB>
+__device__ __forceinline__ void frag_cols(od_frag<bf16_t>& f, const unsigned char* t_rm, const unsigned char*, int c0, int x, int u, int g) {
+    const int cb = (c0 + 4 * (x & 3)) * 2, rr = 32 * u + 4 * g + (x >> 2);
+    const s16x4 a = od_lds_tr_read((const bf16_t*)(t_rm + tile_off<ROWB>(rr, cb)));
+    const s16x4 b = od_lds_tr_read((const bf16_t*)(t_rm + tile_off<ROWB>(rr + 16, cb)));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+template <int ROWB, int TROWB>
+__device__ __forceinline__ void frag_cols(od_frag<float>& f, const unsigned char*, const unsigned char* t_tr, int c0, int x, int u, int g) {
+    frag_perm<TROWB>(f, t_tr, c0 + x, u, g);
+}
+
 // ---- staging a [64 rows][HD] global tile through registers -------------------------------
 template <class T, int HD>
 struct Stage {
@@ -65,6 +81,8 @@ struct Stage {
     static constexpr int NCH = 64 * CPR / 256;              // chunks per thread
     static constexpr int EPC = 16 / (int)sizeof(T);         // elements per chunk
     static constexpr int BYTES = 64 * ROWB;                 // == HD * TROWB
+    static constexpr bool TR = sizeof(T) == 2;              // bf16: transpose at read time (no T tile)
+    static constexpr int NT = TR ? 0 : 1;                   // transposed tiles kept per operand
     u32x4 r[NCH];
 
     // rows row0..row0+63 of a (rows x HD) strip; rows >= nrows are clamped (caller masks)
@@ -107,8 +125,8 @@ inline int attn_grid(int ntiles, int BH) { return ((BH + 7) / 8) * 8 * ntiles; }
 // store 4 consecutive features
 __device__ __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
     u32x2 v;
-    v[0] = (uint32_t)od_f2bf(a) | ((uint32_t)od_f2bf(b) << 16);
-    v[1] = (uint32_t)od_f2bf(c) | ((uint32_t)od_f2bf(d) << 16);
+    v[0] = od_pack_bf2(a, b);
+    v[1] = od_pack_bf2(c, d);
     *(u32x2*)p = v;
 }
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
@@ -117,15 +135,15 @@ __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d
 }
 
 // ======================================================================== forward
-// block: 4 waves x 32 query rows; loop over 64-key tiles.
+// block: 4 waves x 32 query rows; loop over 64-key tiles, double-buffered in LDS.
 template <class T, int HD>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
-                                                        const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
-                                                        float* __restrict__ lse, int B, int H, int L, float scale) {
+__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                                           const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
+                                                           float* __restrict__ lse, int B, int H, int L, float scale) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32;   // 32-deep slabs over the head dim
     constexpr int ND = HD / 16;   // 16-row tiles over the head dim
-    OD_DYN_SMEM(smem);   // 4 * St::BYTES : 2 stages x (K, V^T)
+    OD_DYN_SMEM(smem);   // 2 stages x (K row-major, V row-major [bf16] or V^T [f32])
     const int nqt = (L + 127) / 128;
     int qt, bh;
     if (!attn_block_coords(nqt, B * H, qt, bh)) return;
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const T* __restrict__ q,
         for (int s = 0; s < NS; s++) od_frag_load(fq[qi][s], qb + (size_t)row * ldq + s * 32 + g * 8);
     }
     f32x4 oacc[2][ND];
-    float mrun[2], lrun[2];
+    float mrun[2], lrun[2];      // running max of the RAW scores, running sum
 #pragma unroll
     for (int qi = 0; qi < 2; qi++) {
         mrun[qi] = NEG_BIG; lrun[qi] = 0.f;
@@ -155,8 +173,12 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const T* __restrict__ q,
 
     const int nkt = (L + 63) / 64;
     St sk, sv;
+    auto lstore = [&](unsigned char* base) {
+        sk.store_rowmajor(base);
+        if constexpr (St::TR) sv.store_rowmajor(base + St::BYTES); else sv.store_transposed(base + St::BYTES);
+    };
     sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L);
-    sk.store_rowmajor(smem); sv.store_transposed(smem + St::BYTES);
+    lstore(smem);
     __syncthreads();
     for (int kt = 0; kt < nkt; kt++) {
         const unsigned char* tK = smem + (kt & 1) * 2 * St::BYTES;
@@ -178,35 +200,38 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const T* __restrict__ q,
                 sacc[qi][t4] = a;
             }
         }
-        // online softmax; lane owns query column x, keys 16*t4 + 4g + r
-        od_frag<T> fp[2][2];
         const int kbase = kt * 64;
+        if (kbase + 64 > L) {      // ragged last tile only: mask keys >= L
+#pragma unroll
+            for (int qi = 0; qi < 2; qi++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (kbase + t4 * 16 + 4 * g + r >= L) sacc[qi][t4][r] = NEG_BIG;
+        }
+        // online softmax; lane owns query column x, keys 16*t4 + 4g + r.  p = 2^(c*s - c*m)
+        od_frag<T> fp[2][2];
 #pragma unroll
         for (int qi = 0; qi < 2; qi++) {
-            float mx = NEG_BIG;
+            float mx = fmaxf(fmaxf(sacc[qi][0][0], sacc[qi][0][1]), fmaxf(sacc[qi][0][2], sacc[qi][0][3]));
 #pragma unroll
-            for (int t4 = 0; t4 < 4; t4++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float sv_ = sacc[qi][t4][r] * c;
-                    if (kbase + t4 * 16 + 4 * g + r >= L) sv_ = NEG_BIG;
-                    sacc[qi][t4][r] = sv_;
-                    mx = fmaxf(mx, sv_);
-                }
+            for (int t4 = 1; t4 < 4; t4++)
+                mx = fmaxf(mx, fmaxf(fmaxf(sacc[qi][t4][0], sacc[qi][t4][1]), fmaxf(sacc[qi][t4][2], sacc[qi][t4][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[qi], mx);
-            const float alpha = exp2f(mrun[qi] - mnew);
+            const float alpha = od_exp2((mrun[qi] - mnew) * c);
             mrun[qi] = mnew;
+            const float mc = -mnew * c;
             float ps = 0.f;
 #pragma unroll
-            for (int t4 = 0; t4 < 4; t4++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float p = exp2f(sacc[qi][t4][r] - mnew);
-                    ps += p;
-                    od_frag_set(fp[qi][t4 >> 1], (t4 & 1) * 4 + r, p);
-                }
+            for (int t4 = 0; t4 < 4; t4++) {
+                const float p0 = od_exp2(fmaf(sacc[qi][t4][0], c, mc)), p1 = od_exp2(fmaf(sacc[qi][t4][1], c, mc));
+                const float p2 = od_exp2(fmaf(sacc[qi][t4][2], c, mc)), p3 = od_exp2(fmaf(sacc[qi][t4][3], c, mc));
+                ps += (p0 + p1) + (p2 + p3);
+                od_frag_set4(fp[qi][t4 >> 1], t4 & 1, p0, p1, p2, p3);
+            }
             lrun[qi] = lrun[qi] * alpha + ps;
 #pragma unroll
             for (int dt = 0; dt < ND; dt++) oacc[qi][dt] *= alpha;
@@ -217,14 +242,11 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const T* __restrict__ q,
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 od_frag<T> fv;
-                frag_perm<St::TROWB>(fv, tV, dt * 16 + x, u, g);
+                frag_cols<St::ROWB, St::TROWB>(fv, tV, tV, dt * 16, x, u, g);
 #pragma unroll
                 for (int qi = 0; qi < 2; qi++) oacc[qi][dt] = od_mma(fv, fp[qi][u], oacc[qi][dt]);
             }
-        if (kt + 1 < nkt) {
-            unsigned char* nK = smem + ((kt + 1) & 1) * 2 * St::BYTES;
-            sk.store_rowmajor(nK); sv.store_transposed(nK + St::BYTES);
-        }
+        if (kt + 1 < nkt) lstore(smem + ((kt + 1) & 1) * 2 * St::BYTES);
         __syncthreads();
     }
 #pragma unroll
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const T* __restrict__ q,
 #pragma unroll
             for (int dt = 0; dt < ND; dt++)
                 st4(orow + dt * 16 + 4 * g, oacc[qi][dt][0] * inv, oacc[qi][dt][1] * inv, oacc[qi][dt][2] * inv, oacc[qi][dt][3] * inv);
-            if (g == 0) lse[((size_t)b * H + h) * L + row] = (mrun[qi] + log2f(l)) * LN2;
+            if (g == 0) lse[((size_t)b * H + h) * L + row] = (mrun[qi] * c + log2f(l)) * LN2;
         }
     }
 }
@@ -271,17 +293,18 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 
 // dK, dV: block owns 4 waves x NK*16 keys; loop over 64-query tiles.
 //   S = Q K^T (cols = keys) ; dV^T += dO^T P ; dP = dO V^T ; dS = P*(dP - delta)*scale ; dK^T += Q^T dS
+// LDS per stage: Q, dO row-major (+ Q^T, dO^T for f32); bf16 double-buffers the stage.
 template <class T, int HD, int NK>
-__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
-                                                            const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
-                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            T* __restrict__ dk, int lddk, T* __restrict__ dv, int lddv,
-                                                            int B, int H, int L, float scale) {
+__global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                                               const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               T* __restrict__ dk, int lddk, T* __restrict__ dv, int lddv,
+                                                               int B, int H, int L, float scale) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32, ND = HD / 16, KB = 4 * NK * 16;
-    OD_DYN_SMEM(smem);   // 4 * St::BYTES (Q, Q^T, dO, dO^T) + 512 B (lse, delta)
-    float* s_lse = (float*)(smem + 4 * St::BYTES);
-    float* s_delta = s_lse + 64;
+    constexpr int NSTAGE = St::TR ? 2 : 1;
+    constexpr int STAGE = (2 + 2 * St::NT) * St::BYTES + 512;     // tiles + (lse, delta)
+    OD_DYN_SMEM(smem);
     const int nkt = (L + KB - 1) / KB;
     int ktile, bh;
     if (!attn_block_coords(nkt, B * H, ktile, bh)) return;
@@ -312,10 +335,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const T* __restrict_
 #pragma unroll
         for (int dt = 0; dt < ND; dt++) { dkacc[ki][dt] = (f32x4)(0.f); dvacc[ki][dt] = (f32x4)(0.f); }
 
-    unsigned char* tQ = smem;
-    unsigned char* tQT = smem + St::BYTES;
-    unsigned char* tO = smem + 2 * St::BYTES;
-    unsigned char* tOT = smem + 3 * St::BYTES;
     const int nqt = (L + 63) / 64;
     St sq, so;
     float r_lse = 0.f, r_del = 0.f;
@@ -327,16 +346,29 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const T* __restrict_
             r_del = row < L ? delb[row] : 0.f;
         }
     };
-    auto lstore = [&]() {
-        sq.store_rowmajor(tQ); sq.store_transposed(tQT); so.store_rowmajor(tO); so.store_transposed(tOT);
-        if (threadIdx.x < 64) { s_lse[threadIdx.x] = r_lse * LOG2E; s_delta[threadIdx.x] = r_del; }
+    // stage layout: [Q][dO]([Q^T][dO^T])[lse(64) delta(64)]
+    auto lstore = [&](unsigned char* st) {
+        sq.store_rowmajor(st); so.store_rowmajor(st + St::BYTES);
+        if constexpr (!St::TR) { sq.store_transposed(st + 2 * St::BYTES); so.store_transposed(st + 3 * St::BYTES); }
+        float* sl = (float*)(st + (2 + 2 * St::NT) * St::BYTES);
+        if (threadIdx.x < 64) { sl[threadIdx.x] = r_lse * LOG2E; sl[64 + threadIdx.x] = r_del; }
     };
     gload(0);
-    lstore();
+    lstore(smem);
     __syncthreads();
+    int cur = 0;
+    const bool kragged = ktile * KB + KB > L;
     for (int qt = 0; qt < nqt; qt++) {
         if (qt + 1 < nqt) gload(qt + 1);
+        const unsigned char* st = smem + cur * STAGE;
+        const unsigned char* tQ = st;
+        const unsigned char* tO = st + St::BYTES;
+        const unsigned char* tQT = st + 2 * St::BYTES;     // f32 only
+        const unsigned char* tOT = st + 3 * St::BYTES;     // f32 only
+        const float* s_lse = (const float*)(st + (2 + 2 * St::NT) * St::BYTES);
+        const float* s_delta = s_lse + 64;
         const int qbase = qt * 64;
+        const bool ragged = kragged || (qbase + 64 > L);
         // per 32-query slab u (two 16-row tiles): scores, probabilities, dP, dS
         od_frag<T> fp[NK][2], fds[NK][2];
 #pragma unroll
@@ -354,15 +386,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const T* __restrict_
                 f32x4 sa = (f32x4)(0.f), pa = (f32x4)(0.f);
 #pragma unroll
                 for (int s = 0; s < NS; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
-                const bool kvalid = key0 + ki * 16 + x < L;
+                float p[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const bool valid = kvalid && (qbase + t4 * 16 + 4 * g + r < L);
-                    const float p = valid ? exp2f(sa[r] * c - l4[r]) : 0.f;
-                    const float ds = p * (pa[r] - d4[r]) * scale;
-                    od_frag_set(fp[ki][t4 >> 1], (t4 & 1) * 4 + r, p);
-                    od_frag_set(fds[ki][t4 >> 1], (t4 & 1) * 4 + r, ds);
+                for (int r = 0; r < 4; r++) p[r] = od_exp2(fmaf(sa[r], c, -l4[r]));
+                if (ragged) {
+                    const bool kvalid = key0 + ki * 16 + x < L;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (!(kvalid && (qbase + t4 * 16 + 4 * g + r < L))) p[r] = 0.f;
                 }
+                od_frag_set4(fp[ki][t4 >> 1], t4 & 1, p[0], p[1], p[2], p[3]);
+                od_frag_set4(fds[ki][t4 >> 1], t4 & 1, p[0] * (pa[0] - d4[0]) * scale, p[1] * (pa[1] - d4[1]) * scale,
+                             p[2] * (pa[2] - d4[2]) * scale, p[3] * (pa[3] - d4[3]) * scale);
             }
         }
         // dV^T += dO^T P ; dK^T += Q^T dS     (A rows = features, k = permuted queries, cols = keys)
@@ -371,17 +406,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const T* __restrict_
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 od_frag<T> fot, fqt;
-                frag_perm<St::TROWB>(fot, tOT, dt * 16 + x, u, g);
-                frag_perm<St::TROWB>(fqt, tQT, dt * 16 + x, u, g);
+                frag_cols<St::ROWB, St::TROWB>(fot, tO, tOT, dt * 16, x, u, g);
+                frag_cols<St::ROWB, St::TROWB>(fqt, tQ, tQT, dt * 16, x, u, g);
 #pragma unroll
                 for (int ki = 0; ki < NK; ki++) {
                     dvacc[ki][dt] = od_mma(fot, fp[ki][u], dvacc[ki][dt]);
                     dkacc[ki][dt] = od_mma(fqt, fds[ki][u], dkacc[ki][dt]);
                 }
             }
+        if (NSTAGE == 1) __syncthreads();
+        if (qt + 1 < nqt) lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0));
         __syncthreads();
-        if (qt + 1 < nqt) lstore();
-        __syncthreads();
+        if (NSTAGE == 2) cur ^= 1;
     }
 #pragma unroll
     for (int ki = 0; ki < NK; ki++) {
@@ -401,13 +437,15 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const T* __restrict_
 // dQ: block owns 4 waves x NQ*16 queries; loop over 64-key tiles.
 //   S^T = K Q^T ; dP^T = V dO^T ; dS^T = P^T*(dP^T - delta)*scale ; dQ^T += K^T dS^T
 template <class T, int HD, int NQ>
-__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
-                                                           const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
-                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           T* __restrict__ dq, int lddq, int B, int H, int L, float scale) {
+__global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                                              const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              T* __restrict__ dq, int lddq, int B, int H, int L, float scale) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32, ND = HD / 16, QB = 4 * NQ * 16;
-    OD_DYN_SMEM(smem);   // 3 * St::BYTES : K, K^T, V
+    constexpr int NSTAGE = St::TR ? 2 : 1;
+    constexpr int STAGE = (2 + St::NT) * St::BYTES;      // K, V (+ K^T for f32)
+    OD_DYN_SMEM(smem);
     const int nqt = (L + QB - 1) / QB;
     int qtile, bh;
     if (!attn_block_coords(nqt, B * H, qtile, bh)) return;
@@ -439,17 +477,24 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const T* __restrict__
 #pragma unroll
         for (int dt = 0; dt < ND; dt++) dqacc[qi][dt] = (f32x4)(0.f);
 
-    unsigned char* tK = smem;
-    unsigned char* tKT = smem + St::BYTES;
-    unsigned char* tV = smem + 2 * St::BYTES;
     const int nkt = (L + 63) / 64;
     St sk, sv;
+    auto lstore = [&](unsigned char* st) {
+        sk.store_rowmajor(st); sv.store_rowmajor(st + St::BYTES);
+        if constexpr (!St::TR) sk.store_transposed(st + 2 * St::BYTES);
+    };
     sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L);
-    sk.store_rowmajor(tK); sk.store_transposed(tKT); sv.store_rowmajor(tV);
+    lstore(smem);
     __syncthreads();
+    int cur = 0;
     for (int kt = 0; kt < nkt; kt++) {
         if (kt + 1 < nkt) { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
+        const unsigned char* st = smem + cur * STAGE;
+        const unsigned char* tK = st;
+        const unsigned char* tV = st + St::BYTES;
+        const unsigned char* tKT = st + 2 * St::BYTES;      // f32 only
         const int kbase = kt * 64;
+        const bool ragged = kbase + 64 > L;
         od_frag<T> fds[NQ][2];
 #pragma unroll
         for (int t4 = 0; t4 < 4; t4++) {
@@ -464,12 +509,16 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const T* __restrict__
                 f32x4 sa = (f32x4)(0.f), pa = (f32x4)(0.f);
 #pragma unroll
                 for (int s = 0; s < NS; s++) { sa = od_mma(fkr[s], fq[qi][s], sa); pa = od_mma(fvr[s], fdo[qi][s], pa); }
+                float p[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const bool valid = kbase + t4 * 16 + 4 * g + r < L;
-                    const float p = valid ? exp2f(sa[r] * c - r_lse[qi]) : 0.f;
-                    od_frag_set(fds[qi][t4 >> 1], (t4 & 1) * 4 + r, p * (pa[r] - r_del[qi]) * scale);
+                for (int r = 0; r < 4; r++) p[r] = od_exp2(fmaf(sa[r], c, -r_lse[qi]));
+                if (ragged) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (kbase + t4 * 16 + 4 * g + r >= L) p[r] = 0.f;
                 }
+                od_frag_set4(fds[qi][t4 >> 1], t4 & 1, p[0] * (pa[0] - r_del[qi]) * scale, p[1] * (pa[1] - r_del[qi]) * scale,
+                             p[2] * (pa[2] - r_del[qi]) * scale, p[3] * (pa[3] - r_del[qi]) * scale);
             }
         }
 #pragma unroll
@@ -477,13 +526,14 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const T* __restrict__
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 od_frag<T> fkt;
-                frag_perm<St::TROWB>(fkt, tKT, dt * 16 + x, u, g);
+                frag_cols<St::ROWB, St::TROWB>(fkt, tK, tKT, dt * 16, x, u, g);
 #pragma unroll
                 for (int qi = 0; qi < NQ; qi++) dqacc[qi][dt] = od_mma(fkt, fds[qi][u], dqacc[qi][dt]);
             }
+        if (NSTAGE == 1) __syncthreads();
+        if (kt + 1 < nkt) lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0));
         __syncthreads();
-        if (kt + 1 < nkt) { sk.store_rowmajor(tK); sk.store_transposed(tKT); sv.store_rowmajor(tV); }
-        __syncthreads();
+        if (NSTAGE == 2) cur ^= 1;
     }
 #pragma unroll
     for (int qi = 0; qi < NQ; qi++) {
@@ -515,10 +565,10 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     OD_LAUNCH((attn_delta_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)o, ldo, (const T*)dout, lddo, delta,
               B, H, L, HD);
     const int gk = attn_grid((L + 64 * NK - 1) / (64 * NK), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK>), dim3(gk), dim3(256), (4 * Stage<T, HD>::BYTES + 512), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK>), dim3(gk), dim3(256), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale);
     const int gq = attn_grid((L + 64 * NQ - 1) / (64 * NQ), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ>), dim3(gq), dim3(256), (3 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ>), dim3(gq), dim3(256), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale);
     OD_CHECK_LAUNCH();
     return 0;

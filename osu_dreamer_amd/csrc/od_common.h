@@ -39,7 +39,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float od_bf2f(bf16_t h) {
     union { uint32_t u; float f; } c; c.u = ((uint32_t)h) << 16; return c.f;
 }
-// round-to-nearest-even, NaN preserved
+#if defined(OD_EMU)
+// round-to-nearest-even, NaN preserved (software; the emulator has no v_cvt_pk_bf16_f32)
 __device__ __forceinline__ bf16_t od_f2bf(float f) {
     union { uint32_t u; float f; } c; c.f = f;
     uint32_t u = c.u;
@@ -47,6 +48,19 @@ __device__ __forceinline__ bf16_t od_f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+__device__ __forceinline__ uint32_t od_pack_bf2(float lo, float hi) { return (uint32_t)od_f2bf(lo) | ((uint32_t)od_f2bf(hi) << 16); }
+__device__ __forceinline__ float od_exp2(float x) { return exp2f(x); }
+#else
+// gfx950: float -> bf16 is one v_cvt_pk_bf16_f32 (RNE); exp2 is the raw v_exp_f32
+typedef __bf16 od_bf2_t __attribute__((ext_vector_type(2)));
+typedef float od_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t od_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ uint32_t od_pack_bf2(float lo, float hi) {
+    od_f2_t v; v[0] = lo; v[1] = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, od_bf2_t));
+}
+__device__ __forceinline__ float od_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 
 template <class T> struct od_t;
 template <> struct od_t<float> {
@@ -82,7 +96,7 @@ __device__ __forceinline__ void od_st8(float* p, const float (&v)[8]) {
 __device__ __forceinline__ void od_st8(bf16_t* p, const float (&v)[8]) {
     u32x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = (uint32_t)od_f2bf(v[2 * i]) | ((uint32_t)od_f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; i++) r[i] = od_pack_bf2(v[2 * i], v[2 * i + 1]);
     *(u32x4*)p = r;
 }
 
@@ -121,6 +135,28 @@ __device__ __forceinline__ void od_frag_zero(od_frag<float>& f) {
 }
 __device__ __forceinline__ void od_frag_set(od_frag<bf16_t>& f, int j, float x) { f.v[j] = (short)od_f2bf(x); }
 __device__ __forceinline__ void od_frag_set(od_frag<float>& f, int j, float x) { f.v[j] = x; }
+// elements 4*half .. 4*half+3 of a fragment (half = 0 or 1)
+__device__ __forceinline__ void od_frag_set4(od_frag<bf16_t>& f, int half, float a, float b, float c, float d) {
+    u32x4 w = __builtin_bit_cast(u32x4, f.v);
+    w[2 * half] = od_pack_bf2(a, b);
+    w[2 * half + 1] = od_pack_bf2(c, d);
+    f.v = __builtin_bit_cast(s16x8, w);
+}
+__device__ __forceinline__ void od_frag_set4(od_frag<float>& f, int half, float a, float b, float c, float d) {
+    f.v[4 * half] = a; f.v[4 * half + 1] = b; f.v[4 * half + 2] = c; f.v[4 * half + 3] = d;
+}
+
+// LDS transpose read (gfx950 ds_read_b64_tr_b16): within each 16-lane group, lane c supplies the
+// address of a 4-element chunk; lane i receives element (i&3) of chunks (i>>2) + 4j, j = 0..3
+// (semantics measured on hardware with tools/probes/tr_probe.hip).  With lane c pointing at
+// tile[r0 + (c>>2)][c0 + 4*(c&3)], lane i gets tile[r0 + j][c0 + i], j = 0..3: a column of 4 rows.
+#if defined(OD_EMU)
+__device__ __forceinline__ s16x4 od_lds_tr_read(const bf16_t* p) { return emu::ds_read_tr16_b64(p); }
+#else
+__device__ __forceinline__ s16x4 od_lds_tr_read(const bf16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+#endif
 
 __device__ __forceinline__ f32x4 od_mma(const od_frag<bf16_t>& a, const od_frag<bf16_t>& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);

@@ -247,6 +247,27 @@ inline emu_f32x16 mfma_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c) {
 }
 }  // namespace emu
 
+namespace emu {
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16 as measured on gfx950 (tools/probes/tr_probe.hip): in each 16-lane group lane i
+// gets element (i&3) of the chunks supplied by lanes (i>>2) + 4j, j = 0..3.
+inline s16x4_t ds_read_tr16_b64(const unsigned short* p) {
+    State& s = S();
+    int w = wave_id(), l = lane_id();
+    memcpy(s.xbuf[w][l], &p, sizeof(p));
+    wave_barrier();
+    s16x4_t r;
+    const int grp = l & ~15, i = l & 15;
+    for (int j = 0; j < 4; j++) {
+        const unsigned short* q;
+        memcpy(&q, s.xbuf[w][grp + (i >> 2) + 4 * j], sizeof(q));
+        r[j] = (short)q[i & 3];
+    }
+    wave_barrier();
+    return r;
+}
+}  // namespace emu
+
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4_f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
