@@ -38,9 +38,10 @@ const char* od_error_string(int code);
  *           model.py:45 (proj_audio), and their autograd backward-data. */
 int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                int M, int N, int K, int epilogue, int accumulate, void* stream);
-/* dW[N,K] (fp32, ld lddw) += G[M,N]^T A[M,K]   — autograd weight gradient of the above. */
-int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, int M, int N, int K,
-               void* stream);
+/* dW[N,K] (fp32, ld lddw) += G[M,N]^T A[M,K]; if dbias != NULL also dbias[N] += column sums of G
+ * — autograd weight and bias gradients of the above, G read once. */
+int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M, int N,
+               int K, void* stream);
 /* out[N] (fp32) += column sums of G[M,N]        — autograd bias gradient. */
 int od_colsum(int dtype, const void* G, int ldg, float* out, int M, int N, void* stream);
 /* dst[Np,Kp] (dtype, zero padded) = src[N,K] fp32 (transpose=0) or dst[Kp,Np] = src^T (transpose=1);

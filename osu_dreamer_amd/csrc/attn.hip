@@ -13,64 +13,15 @@
 // which the other operand reproduces by reading a TRANSPOSED LDS tile with two half-width
 // reads.  fwd:  S^T = K Q^T ;  O^T += V^T P^T.
 #include "od_common.h"
+#include "od_tiles.h"
 #include "od_api_internal.h"
+#include <type_traits>
 
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;
-
-// ---- swizzled LDS tile addressing: 16-byte slots XORed with the row index ---------------
-template <int ROWB>
-__device__ __forceinline__ int tile_off(int row, int byte) {
-    constexpr int NS = ROWB / 16;
-    return row * ROWB + ((((byte >> 4)) ^ (row & (NS - 1))) << 4) + (byte & 15);
-}
-
-// 8 k-contiguous elements of `row` starting at element k0 (multiple of 8)
-template <int ROWB>
-__device__ __forceinline__ void frag_contig(od_frag<bf16_t>& f, const unsigned char* t, int row, int k0) {
-    f.v = *(const s16x8*)(t + tile_off<ROWB>(row, k0 * 2));
-}
-template <int ROWB>
-__device__ __forceinline__ void frag_contig(od_frag<float>& f, const unsigned char* t, int row, int k0) {
-    const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4));
-    const f32x4 b = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4 + 16));
-    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
-}
-// permuted slab u: elements {32u+4g .. +3} and {32u+16+4g .. +3} of `row`
-template <int ROWB>
-__device__ __forceinline__ void frag_perm(od_frag<bf16_t>& f, const unsigned char* t, int row, int u, int g) {
-    const s16x4 a = *(const s16x4*)(t + tile_off<ROWB>(row, (32 * u + 4 * g) * 2));
-    const s16x4 b = *(const s16x4*)(t + tile_off<ROWB>(row, (32 * u + 16 + 4 * g) * 2));
-    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
-}
-template <int ROWB>
-__device__ __forceinline__ void frag_perm(od_frag<float>& f, const unsigned char* t, int row, int u, int g) {
-    const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, (32 * u + 4 * g) * 4));
-    const f32x4 b = *(const f32x4*)(t + tile_off<ROWB>(row, (32 * u + 16 + 4 * g) * 4));
-    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
-}
-
-// "column" fragment: element j of lane (x, g) = tile[row 32u + 16*(j>>2) + 4g + (j&3)][col c0 + x].
-// bf16: two LDS transpose reads (ds_read_b64_tr_b16) from the ROW-MAJOR tile — no transposed copy
-// of the tile exists.  f32: two 16-byte reads from a transposed tile written at staging time.
-template <int ROWB, int TROWB>
-__device__ __forceinline__ void frag_cols(od_frag<bf16_t>& f, const unsigned char* t_rm, const unsigned char*, int c0, int x, int u, int g) {
-    const int cb = (c0 + 4 * (x & 3)) * 2, rr = 32 * u + 4 * g + (x >> 2);
-    const s16x4 a = od_lds_tr_read((const bf16_t*)(t_rm + tile_off<ROWB>(rr, cb)));
-    const s16x4 b = od_lds_tr_read((const bf16_t*)(t_rm + tile_off<ROWB>(rr + 16, cb)));
-    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
-}
-template <int ROWB, int TROWB>
-__device__ __forceinline__ void frag_cols(od_frag<float>& f, const unsigned char*, const unsigned char* t_tr, int c0, int x, int u, int g) {
-    frag_perm<TROWB>(f, t_tr, c0 + x, u, g);
-}
 
 // ---- staging a [64 rows][HD] global tile through registers -------------------------------
 template <class T, int HD>
@@ -180,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
     sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L);
     lstore(smem);
     __syncthreads();
-    for (int kt = 0; kt < nkt; kt++) {
+    auto tile = [&](int kt, auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
         const unsigned char* tK = smem + (kt & 1) * 2 * St::BYTES;
         const unsigned char* tV = tK + St::BYTES;
         if (kt + 1 < nkt) { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
@@ -201,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
             }
         }
         const int kbase = kt * 64;
-        if (kbase + 64 > L) {      // ragged last tile only: mask keys >= L
+        if constexpr (MASKED) {    // ragged last tile only: mask keys >= L
 #pragma unroll
             for (int qi = 0; qi < 2; qi++)
 #pragma unroll
@@ -248,7 +200,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
             }
         if (kt + 1 < nkt) lstore(smem + ((kt + 1) & 1) * 2 * St::BYTES);
         __syncthreads();
-    }
+    };
+    const int nfull = L / 64;
+    for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nfull, std::true_type{});
 #pragma unroll
     for (int qi = 0; qi < 2; qi++) {
         float l = lrun[qi];
@@ -358,7 +313,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
     __syncthreads();
     int cur = 0;
     const bool kragged = ktile * KB + KB > L;
-    for (int qt = 0; qt < nqt; qt++) {
+    auto tile = [&](int qt, auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
         if (qt + 1 < nqt) gload(qt + 1);
         const unsigned char* st = smem + cur * STAGE;
         const unsigned char* tQ = st;
@@ -368,7 +324,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
         const float* s_lse = (const float*)(st + (2 + 2 * St::NT) * St::BYTES);
         const float* s_delta = s_lse + 64;
         const int qbase = qt * 64;
-        const bool ragged = kragged || (qbase + 64 > L);
         // per 32-query slab u (two 16-row tiles): scores, probabilities, dP, dS
         od_frag<T> fp[NK][2], fds[NK][2];
 #pragma unroll
@@ -389,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
                 float p[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) p[r] = od_exp2(fmaf(sa[r], c, -l4[r]));
-                if (ragged) {
+                if constexpr (MASKED) {
                     const bool kvalid = key0 + ki * 16 + x < L;
 #pragma unroll
                     for (int r = 0; r < 4; r++)
@@ -418,7 +373,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
         if (qt + 1 < nqt) lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0));
         __syncthreads();
         if (NSTAGE == 2) cur ^= 1;
-    }
+    };
+    const int nfull = kragged ? 0 : L / 64;
+    for (int qt = 0; qt < nfull; qt++) tile(qt, std::false_type{});
+    for (int qt = nfull; qt < nqt; qt++) tile(qt, std::true_type{});
 #pragma unroll
     for (int ki = 0; ki < NK; ki++) {
         const int row = key0 + ki * 16 + x;
@@ -487,14 +445,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
     lstore(smem);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nkt; kt++) {
+    auto tile = [&](int kt, auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
         if (kt + 1 < nkt) { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
         const unsigned char* st = smem + cur * STAGE;
         const unsigned char* tK = st;
         const unsigned char* tV = st + St::BYTES;
         const unsigned char* tKT = st + 2 * St::BYTES;      // f32 only
         const int kbase = kt * 64;
-        const bool ragged = kbase + 64 > L;
         od_frag<T> fds[NQ][2];
 #pragma unroll
         for (int t4 = 0; t4 < 4; t4++) {
@@ -512,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
                 float p[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) p[r] = od_exp2(fmaf(sa[r], c, -r_lse[qi]));
-                if (ragged) {
+                if constexpr (MASKED) {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         if (kbase + t4 * 16 + 4 * g + r >= L) p[r] = 0.f;
@@ -534,7 +492,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
         if (kt + 1 < nkt) lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0));
         __syncthreads();
         if (NSTAGE == 2) cur ^= 1;
-    }
+    };
+    const int nfull = L / 64;
+    for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nfull, std::true_type{});
 #pragma unroll
     for (int qi = 0; qi < NQ; qi++) {
         const int row = q0 + qi * 16 + x;

@@ -10,6 +10,7 @@
 // XOR swizzle, register-staged prefetch of the next slab under the MFMAs, and an
 // epilogue staged through LDS so global stores are 16/32-byte rows.
 #include "od_common.h"
+#include "od_tiles.h"
 #include "od_api_internal.h"
 
 namespace {
@@ -175,12 +176,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 }
 
 // ---- TN: dW[n][k] += sum_m G[m][n] * A[m][k] over this block's M range ----------
+// The reduction index m is the slow (row) dimension of both operands.  bf16: the slab is staged
+// ROW-MAJOR ([m][128 cols], coalesced 16-byte writes) and the MFMA fragments — which need 8
+// different m per lane — come from LDS transpose reads (ds_read_b64_tr_b16).  f32 (no 32-bit
+// transpose read): the slab is transposed while it is written to LDS.
+// Blocks of k-tile 0 also accumulate the column sums of G (the bias gradient) from the registers
+// they stage, so G is not read a second time.
 template <class T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ A, int lda,
-                                                      float* __restrict__ dW, int lddw, int M, int N, int K, int m_per_block) {
+                                                      float* __restrict__ dW, int lddw, float* __restrict__ dbias,
+                                                      int M, int N, int K, int m_per_block) {
+    constexpr bool TR = sizeof(T) == 2;
     constexpr int BR = 128 / (int)sizeof(T);  // reduction rows per slab (64 bf16 / 32 f32)
     constexpr int CH = 16 / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+    __shared__ float sred[128];
     const int tiles_n = (N + BN - 1) / BN, tiles_k = (K + BM - 1) / BM;
     const int tile = blockIdx.x % (tiles_n * tiles_k), split = blockIdx.x / (tiles_n * tiles_k);
     const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BM;
@@ -189,6 +199,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
     if (mb >= M) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const bool do_bias = dbias != nullptr && (tile % tiles_k) == 0;
+    if (tid < 128) sred[tid] = 0.f;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -196,10 +208,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4)(0.f);
 
-    // a slab is BR rows x 128 columns of each operand = BR*128/CH chunks = 2048 (bf16: 64*16) / 1024 (f32: 32*32)
-    constexpr int CPR = 128 / CH;              // chunks per row
-    constexpr int NCH = BR * CPR / 256;        // chunks per thread per operand
+    constexpr int CPR = 128 / CH;              // 16-byte chunks per slab row (16 bf16 / 32 f32)
+    constexpr int NCH = BR * CPR / 256;        // chunks per thread per operand (4)
     u32x4 rg[NCH], ra[NCH];
+    float bsum[CH];
+#pragma unroll
+    for (int e = 0; e < CH; e++) bsum[e] = 0.f;
     const int nslab = (me - mb + BR - 1) / BR;
 
     auto gload = [&](int st) {
@@ -211,24 +225,54 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
             rg[i] = (mv && n0 + cc < N) ? *(const u32x4*)(G + (size_t)m * ldg + n0 + cc) : (u32x4)(0u);
             ra[i] = (mv && k0 + cc < K) ? *(const u32x4*)(A + (size_t)m * lda + k0 + cc) : (u32x4)(0u);
         }
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const T* pg = (const T*)&rg[i];
+#pragma unroll
+                for (int e = 0; e < CH; e++) bsum[e] += od_t<T>::ld(pg + e);
+            }
+        }
     };
-    // transposing store: element (r, col) of the slab -> LDS row `col`, reduction index r
     auto lstore = [&](int buf) {
-        unsigned char* sA = smem + buf * STAGE_BYTES;   // G^T : rows = n
-        unsigned char* sB = sA + 16384;                  // A^T : rows = k
+        unsigned char* sA = smem + buf * STAGE_BYTES;   // G slab
+        unsigned char* sB = sA + 16384;                  // A slab
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
             const int c = tid + 256 * i, r = c / CPR, cc = (c % CPR) * CH;
-            const T* pg = (const T*)&rg[i];
-            const T* pa = (const T*)&ra[i];
-            const int rb = r * (int)sizeof(T);
+            if constexpr (TR) {                          // row-major [m][128], 256-byte rows
+                *(u32x4*)(sA + tile_off<256>(r, cc * 2)) = rg[i];
+                *(u32x4*)(sB + tile_off<256>(r, cc * 2)) = ra[i];
+            } else {                                     // transposed [col][m], 128-byte rows
+                const T* pg = (const T*)&rg[i];
+                const T* pa = (const T*)&ra[i];
 #pragma unroll
-            for (int e = 0; e < CH; e++) {
-                const int row = cc + e;
-                const int off = row * 128 + ((((rb >> 4)) ^ (row & 7)) << 4) + (rb & 15);
-                *(T*)(sA + off) = pg[e];
-                *(T*)(sB + off) = pa[e];
+                for (int e = 0; e < CH; e++) {
+                    *(T*)(sA + tile_off<128>(cc + e, r * (int)sizeof(T))) = pg[e];
+                    *(T*)(sB + tile_off<128>(cc + e, r * (int)sizeof(T))) = pa[e];
+                }
             }
+        }
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* sA = smem + buf * STAGE_BYTES;
+        const unsigned char* sB = sA + 16384;
+        if constexpr (TR) {
+            const int x = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                od_frag<T> fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) frag_cols<256, 0>(fa[i], sA, sA, wm * 64 + i * 16, x, u, g);
+#pragma unroll
+                for (int j = 0; j < 4; j++) frag_cols<256, 0>(fb[j], sB, sB, wn * 64 + j * 16, x, u, g);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] = od_mma(fa[i], fb[j], acc[i][j]);
+            }
+        } else {
+            compute_stage<T>(sA, sB, wm, wn, lane, acc);
         }
     };
 
@@ -238,12 +282,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
     for (int st = 0; st < nslab; st++) {
         const int buf = st & 1;
         if (st + 1 < nslab) gload(st + 1);
-        compute_stage<T>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+        compute(buf);
         if (st + 1 < nslab) lstore(buf ^ 1);
         __syncthreads();
     }
-    // NOTE rows of the G^T panel whose n >= N were never written with real data: they were
-    // loaded as zeros (predicate above), so the out-of-range accumulators are simply dropped.
     const int col = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -254,6 +296,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
                 const int n = n0 + wm * 64 + i * 16 + g * 4 + r, k = k0 + wn * 64 + j * 16 + col;
                 if (n < N && k < K) atomicAdd(dW + (size_t)n * lddw + k, acc[i][j][r]);
             }
+    if (do_bias) {
+        const int cc = (tid % CPR) * CH;
+#pragma unroll
+        for (int e = 0; e < CH; e++) atomicAdd(&sred[cc + e], bsum[e]);
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) atomicAdd(dbias + n0 + tid, sred[tid]);
+    }
 }
 
 // column sums (bias gradients): out[n] += sum_m G[m][n]
@@ -283,7 +332,7 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
 }
 
 template <class T>
-int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, int M, int N, int K, hipStream_t st) {
+int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, float* dbias, int M, int N, int K, hipStream_t st) {
     constexpr int BR = 128 / (int)sizeof(T);
     const int tiles = ((N + BN - 1) / BN) * ((K + BM - 1) / BM);
     int splits = (2048 + tiles - 1) / tiles;                 // aim for ~2048 workgroups (8 per CU)
@@ -291,7 +340,7 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, int
     mpb = ((mpb + BR - 1) / BR) * BR;
     if (mpb < 4 * BR) mpb = 4 * BR;
     splits = (M + mpb - 1) / mpb;
-    OD_LAUNCH((gemm_tn_kernel<T>), dim3(tiles * splits), dim3(256), 0, st, G, ldg, A, lda, dW, lddw, M, N, K, mpb);
+    OD_LAUNCH((gemm_tn_kernel<T>), dim3(tiles * splits), dim3(256), 0, st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb);
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -310,13 +359,13 @@ extern "C" int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int 
     return OD_ERR_ARG;
 }
 
-extern "C" int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, int M, int N, int K,
-                          void* stream) {
+extern "C" int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M,
+                          int N, int K, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return OD_ERR_ARG;
     const int ch = dtype == OD_BF16 ? 8 : 4;
     if (ldg % ch || lda % ch) return OD_ERR_ALIGN;
-    if (dtype == OD_BF16) return launch_tn<bf16_t>((const bf16_t*)G, ldg, (const bf16_t*)A, lda, dW, lddw, M, N, K, (hipStream_t)stream);
-    if (dtype == OD_F32) return launch_tn<float>((const float*)G, ldg, (const float*)A, lda, dW, lddw, M, N, K, (hipStream_t)stream);
+    if (dtype == OD_BF16) return launch_tn<bf16_t>((const bf16_t*)G, ldg, (const bf16_t*)A, lda, dW, lddw, dbias, M, N, K, (hipStream_t)stream);
+    if (dtype == OD_F32) return launch_tn<float>((const float*)G, ldg, (const float*)A, lda, dW, lddw, dbias, M, N, K, (hipStream_t)stream);
     return OD_ERR_ARG;
 }
 

@@ -172,19 +172,25 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, in
 }
 
 // backward: dx[l] = sum_j w[j] dy[l - j + R];  dw[j] += sum_l dy[l] x[l + j - R];  db += sum_l dy[l]
+// The per-channel weight/bias sums are reduced across the block in LDS before they touch global
+// atomics (one atomic per (channel, tap) per block instead of per thread).
+constexpr int DW_RUN_BWD = 64;
 template <class T, int KS>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                          const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx,
                                                          float* __restrict__ dw, float* __restrict__ db, int L, int C) {
     constexpr int R = KS / 2;
+    __shared__ float red[1024 * (KS + 1)];
     const int cg = C / 8;
     const int b = blockIdx.y;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const int cgi = (int)(t % cg);
     const long run = t / cg;
-    const int l0 = (int)(run * DW_RUN);
-    if (l0 >= L) return;
+    const int l0 = (int)(run * DW_RUN_BWD);
+    const bool active = l0 < L;
     const int c = cgi * 8;
+    for (int i = threadIdx.x; i < C * (KS + 1); i += 256) red[i] = 0.f;
+    __syncthreads();
     float wv[8][KS], adw[8][KS], adb[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -192,52 +198,62 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x
 #pragma unroll
         for (int j = 0; j < KS; j++) { wv[k][j] = w[(size_t)(c + k) * KS + j]; adw[k][j] = 0.f; }
     }
-    // windows over frames l-R .. l+R of both dy (for dx) and x (for dw)
-    float wy[KS][8], wx[KS][8];
-    const T* xb = x + (size_t)b * L * ldx + c;
-    const T* yb = dy + (size_t)b * L * lddy + c;
+    if (active) {
+        // windows over frames l-R .. l+R of both dy (for dx) and x (for dw)
+        float wy[KS][8], wx[KS][8];
+        const T* xb = x + (size_t)b * L * ldx + c;
+        const T* yb = dy + (size_t)b * L * lddy + c;
 #pragma unroll
-    for (int j = 0; j < KS - 1; j++) {
-        const int l = l0 - R + j;
-        if (l >= 0 && l < L) { od_ld8(xb + (size_t)l * ldx, wx[j]); od_ld8(yb + (size_t)l * lddy, wy[j]); }
-        else {
+        for (int j = 0; j < KS - 1; j++) {
+            const int l = l0 - R + j;
+            if (l >= 0 && l < L) { od_ld8(xb + (size_t)l * ldx, wx[j]); od_ld8(yb + (size_t)l * lddy, wy[j]); }
+            else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) { wx[j][k] = 0.f; wy[j][k] = 0.f; }
+                for (int k = 0; k < 8; k++) { wx[j][k] = 0.f; wy[j][k] = 0.f; }
+            }
         }
-    }
-    for (int i = 0; i < DW_RUN; i++) {
-        const int l = l0 + i;
-        if (l >= L) break;
-        const int ln = l + R;
-        if (ln < L) { od_ld8(xb + (size_t)ln * ldx, wx[KS - 1]); od_ld8(yb + (size_t)ln * lddy, wy[KS - 1]); }
-        else {
+        for (int i = 0; i < DW_RUN_BWD; i++) {
+            const int l = l0 + i;
+            if (l >= L) break;
+            const int ln = l + R;
+            if (ln < L) { od_ld8(xb + (size_t)ln * ldx, wx[KS - 1]); od_ld8(yb + (size_t)ln * lddy, wy[KS - 1]); }
+            else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) { wx[KS - 1][k] = 0.f; wy[KS - 1][k] = 0.f; }
+                for (int k = 0; k < 8; k++) { wx[KS - 1][k] = 0.f; wy[KS - 1][k] = 0.f; }
+            }
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float sacc = 0.f;
+                // window slot j holds frame l - R + j; dx[l] += w[jj] * dy[l - jj + R]  ->  slot = 2R - jj
+#pragma unroll
+                for (int jj = 0; jj < KS; jj++) sacc += wv[k][jj] * wy[KS - 1 - jj][k];
+                o[k] = sacc;
+                const float gy = wy[R][k];     // dy[l]
+                adb[k] += gy;
+#pragma unroll
+                for (int jj = 0; jj < KS; jj++) adw[k][jj] += gy * wx[jj][k];   // x[l + jj - R]
+            }
+            od_st8(dx + ((size_t)b * L + l) * lddx + c, o);
+#pragma unroll
+            for (int j = 0; j < KS - 1; j++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) { wx[j][k] = wx[j + 1][k]; wy[j][k] = wy[j + 1][k]; }
         }
-        float o[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            float s = 0.f;
-            // window slot j holds frame l - R + j; dx[l] += w[jj] * dy[l - jj + R]  ->  slot = 2R - jj
+            atomicAdd(&red[(c + k) * (KS + 1) + KS], adb[k]);
 #pragma unroll
-            for (int jj = 0; jj < KS; jj++) s += wv[k][jj] * wy[KS - 1 - jj][k];
-            o[k] = s;
-            const float g = wy[R][k];     // dy[l]
-            adb[k] += g;
-#pragma unroll
-            for (int jj = 0; jj < KS; jj++) adw[k][jj] += g * wx[jj][k];   // x[l + jj - R]
+            for (int j = 0; j < KS; j++) atomicAdd(&red[(c + k) * (KS + 1) + j], adw[k][j]);
         }
-        od_st8(dx + ((size_t)b * L + l) * lddx + c, o);
-#pragma unroll
-        for (int j = 0; j < KS - 1; j++)
-#pragma unroll
-            for (int k = 0; k < 8; k++) { wx[j][k] = wx[j + 1][k]; wy[j][k] = wy[j + 1][k]; }
     }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        atomicAdd(db + c + k, adb[k]);
-#pragma unroll
-        for (int j = 0; j < KS; j++) atomicAdd(dw + (size_t)(c + k) * KS + j, adw[k][j]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * (KS + 1); i += 256) {
+        const int ch = i / (KS + 1), j = i % (KS + 1);
+        const float v = red[i];
+        if (v != 0.f) {
+            if (j == KS) atomicAdd(db + ch, v); else atomicAdd(dw + (size_t)ch * KS + j, v);
+        }
     }
 }
 
@@ -376,7 +392,8 @@ extern "C" int od_dwconv(int dtype, const void* x, int ldx, const float* w, cons
 extern "C" int od_dwconv_bwd(int dtype, const void* x, int ldx, const float* w, const void* dy, int lddy, void* dx, int lddx,
                              float* dw, float* db, int B, int L, int C, int ksize, void* stream) {
     if (C % 8 || ldx % 8 || lddy % 8 || lddx % 8) return OD_ERR_ALIGN;
-    const long threads = (long)(C / 8) * ((L + DW_RUN - 1) / DW_RUN);
+    if (C > 1024) return OD_ERR_UNSUPPORTED;
+    const long threads = (long)(C / 8) * ((L + DW_RUN_BWD - 1) / DW_RUN_BWD);
     dim3 grid((unsigned)((threads + 255) / 256), B);
     if (ksize == 5) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 5>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
     else if (ksize == 3) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 3>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));

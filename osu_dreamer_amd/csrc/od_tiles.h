@@ -1,0 +1,55 @@
+// Swizzled LDS tile addressing and MFMA fragment readers shared by the attention and GEMM kernels.
+#pragma once
+#include "od_common.h"
+
+// ---- swizzled LDS tile addressing: 16-byte slots XORed with the row index ---------------
+template <int ROWB>
+__device__ __forceinline__ int tile_off(int row, int byte) {
+    constexpr int NS = ROWB / 16;
+    return row * ROWB + ((((byte >> 4)) ^ (row & (NS - 1))) << 4) + (byte & 15);
+}
+
+// 8 k-contiguous elements of `row` starting at element k0 (multiple of 8)
+template <int ROWB>
+__device__ __forceinline__ void frag_contig(od_frag<bf16_t>& f, const unsigned char* t, int row, int k0) {
+    f.v = *(const s16x8*)(t + tile_off<ROWB>(row, k0 * 2));
+}
+template <int ROWB>
+__device__ __forceinline__ void frag_contig(od_frag<float>& f, const unsigned char* t, int row, int k0) {
+    const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4));
+    const f32x4 b = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4 + 16));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+// permuted slab u: elements {32u+4g .. +3} and {32u+16+4g .. +3} of `row`
+template <int ROWB>
+__device__ __forceinline__ void frag_perm(od_frag<bf16_t>& f, const unsigned char* t, int row, int u, int g) {
+    const s16x4 a = *(const s16x4*)(t + tile_off<ROWB>(row, (32 * u + 4 * g) * 2));
+    const s16x4 b = *(const s16x4*)(t + tile_off<ROWB>(row, (32 * u + 16 + 4 * g) * 2));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+template <int ROWB>
+__device__ __forceinline__ void frag_perm(od_frag<float>& f, const unsigned char* t, int row, int u, int g) {
+    const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, (32 * u + 4 * g) * 4));
+    const f32x4 b = *(const f32x4*)(t + tile_off<ROWB>(row, (32 * u + 16 + 4 * g) * 4));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+
+// "column" fragment: element j of lane (x, g) = tile[row 32u + 16*(j>>2) + 4g + (j&3)][col c0 + x].
+// bf16: two LDS transpose reads (ds_read_b64_tr_b16) from the ROW-MAJOR tile — no transposed copy
+// of the tile exists.  f32: two 16-byte reads from a transposed tile written at staging time.
+template <int ROWB, int TROWB>
+__device__ __forceinline__ void frag_cols(od_frag<bf16_t>& f, const unsigned char* t_rm, const unsigned char*, int c0, int x, int u, int g) {
+    const int cb = (c0 + 4 * (x & 3)) * 2, rr = 32 * u + 4 * g + (x >> 2);
+    const s16x4 a = od_lds_tr_read((const bf16_t*)(t_rm + tile_off<ROWB>(rr, cb)));
+    const s16x4 b = od_lds_tr_read((const bf16_t*)(t_rm + tile_off<ROWB>(rr + 16, cb)));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+template <int ROWB, int TROWB>
+__device__ __forceinline__ void frag_cols(od_frag<float>& f, const unsigned char*, const unsigned char* t_tr, int c0, int x, int u, int g) {
+    frag_perm<TROWB>(f, t_tr, c0 + x, u, g);
+}
+

@@ -269,24 +269,21 @@ class DenoiserEngine:
             dssg2.zero_()
             # ---- feed-forward branch
             ops.rmsnorm_gate_residual_bwd(t[f"fo.{i}"], t[f"inv5.{i}"], ssg2, dx, dbr, dssg2, B, L)
-            ops.gemm_tn(dbr, t[f"hh.{i}"], self.G(p + "ffn.proj_o.weight"), n_cols=D, k_cols=Hf)
-            ops.colsum(dbr, self.G(p + "ffn.proj_o.bias"))
+            ops.gemm_tn(dbr, t[f"hh.{i}"], self.G(p + "ffn.proj_o.weight"), n_cols=D, k_cols=Hf,
+                        dbias=self.G(p + "ffn.proj_o.bias"))
             ops.gemm_nt(dbr, self.W(p + "ffn.proj_o", T=True), None, dhh)
             ops.swiglu_rmsnorm_bwd(t[f"vg.{i}"], t[f"inv4.{i}"], dhh, dvg, Hf, Hp)
             gw, gb = self.G(p + "ffn.proj_vg.1.weight"), self.G(p + "ffn.proj_vg.1.bias")
             hdw = t[f"hdw.{i}"]
-            ops.gemm_tn(dvg[:, :Hp], hdw, gw[:Hf], n_cols=Hf, k_cols=D)
-            ops.gemm_tn(dvg[:, Hp:], hdw, gw[Hf:], n_cols=Hf, k_cols=D)
-            ops.colsum(dvg[:, :Hp], gb[:Hf], n_cols=Hf)
-            ops.colsum(dvg[:, Hp:], gb[Hf:], n_cols=Hf)
+            ops.gemm_tn(dvg[:, :Hp], hdw, gw[:Hf], n_cols=Hf, k_cols=D, dbias=gb[:Hf])
+            ops.gemm_tn(dvg[:, Hp:], hdw, gw[Hf:], n_cols=Hf, k_cols=D, dbias=gb[Hf:])
             ops.gemm_nt(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dtmp)
             ops.dwconv_bwd(t[f"h2.{i}"], self.P(p + "ffn.proj_vg.0.weight"), dtmp, dbr,
                            self.G(p + "ffn.proj_vg.0.weight"), self.G(p + "ffn.proj_vg.0.bias"), B, L, self.ksize)
             ops.rmsnorm_film_bwd(t[f"x_mid.{i}"], t[f"inv3.{i}"], ssg2, dbr, dx, dssg2, B, L)
             # ---- attention branch
             ops.rmsnorm_gate_residual_bwd(t[f"ao.{i}"], t[f"inv2.{i}"], ssg1, dx, dbr, dssg1, B, L)
-            ops.gemm_tn(dbr, t[f"y.{i}"], self.G(p + "attn.out_proj.weight"))
-            ops.colsum(dbr, self.G(p + "attn.out_proj.bias"))
+            ops.gemm_tn(dbr, t[f"y.{i}"], self.G(p + "attn.out_proj.weight"), dbias=self.G(p + "attn.out_proj.bias"))
             ops.gemm_nt(dbr, self.W(p + "attn.out_proj", T=True), None, dy)
             qk, qkv = t[f"qk.{i}"], t[f"qkv.{i}"]
             ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], t[f"y.{i}"], dy, t[f"lse.{i}"], delta,
@@ -294,11 +291,9 @@ class DenoiserEngine:
             ops.qk_norm_rope_bwd(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, dqk, dqkv,
                                  self.G(p + "attn.q_norm.weight"), self.G(p + "attn.k_norm.weight"), B, L, self.H,
                                  self.hd, FP32_EPS)
-            ops.gemm_tn(dqkv, t[f"h1.{i}"], self.G(p + "attn.qkv_proj.weight"))
-            ops.colsum(dqkv, self.G(p + "attn.qkv_proj.bias"))
+            ops.gemm_tn(dqkv, t[f"h1.{i}"], self.G(p + "attn.qkv_proj.weight"), dbias=self.G(p + "attn.qkv_proj.bias"))
             ops.gemm_nt(dqkv, self.W(p + "attn.qkv_proj", T=True), None, dtmp)      # d h1 (== d cl)
-            ops.gemm_tn(dtmp, a, self.G(p + "proj_cl.weight"))
-            ops.colsum(dtmp, self.G(p + "proj_cl.bias"))
+            ops.gemm_tn(dtmp, a, self.G(p + "proj_cl.weight"), dbias=self.G(p + "proj_cl.bias"))
             ops.gemm_nt(dtmp, self.W(p + "proj_cl", T=True), None, da, accumulate=(i != self.depth - 1))
             ops.rmsnorm_film_bwd(t[f"x_in.{i}"], t[f"inv1.{i}"], ssg1, dtmp, dx, dssg1, B, L)
             # ---- the two modulation linears of this layer
@@ -313,8 +308,7 @@ class DenoiserEngine:
         ops.proj_in_bwd(xt, dx, self.G("proj_in.weight"), self.G("proj_in.bias"))
         da_pre = self.buf("d.a_pre", (self.Ma, A))
         ops.silu_bwd(self.ws.t["a_pre"], da, da_pre)
-        ops.gemm_tn(da_pre, self.ws.t["a_t"], self.G("proj_audio.0.weight"))
-        ops.colsum(da_pre, self.G("proj_audio.0.bias"))
+        ops.gemm_tn(da_pre, self.ws.t["a_t"], self.G("proj_audio.0.weight"), dbias=self.G("proj_audio.0.bias"))
         ops.linear_small_bwd(style, self.P("proj_style.0.weight"), self.ws.t["cg_pre"], dcg,
                              self.buf("d.lin_pre_style", (B, self.Cg), f32), self.G("proj_style.0.weight"),
                              self.G("proj_style.0.bias"), None, False, OD_ACT_SILU)

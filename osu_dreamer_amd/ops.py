@@ -51,13 +51,15 @@ def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False):
                           epilogue, int(accumulate), _stream(A))
 
 
-def gemm_tn(G, A, dW, n_cols=None, k_cols=None):
-    """dW[N,K] += G[:, :N]^T A[:, :K];  dW is any fp32 tensor viewed as [N, K] rows."""
+def gemm_tn(G, A, dW, n_cols=None, k_cols=None, dbias=None):
+    """dW[N,K] += G[:, :N]^T A[:, :K] (and dbias[N] += column sums of G);  dW is any fp32 tensor
+    viewed as [N, K] rows."""
     M = G.shape[0]
     N = n_cols if n_cols is not None else G.shape[1]
     K = k_cols if k_cols is not None else A.shape[1]
     assert dW.dtype == torch.float32 and dW.is_contiguous() and dW.numel() == N * K
-    _lib.lib().od_gemm_tn(dt_code(G.dtype), _p(G), _ld(G), _p(A), _ld(A), _p(dW), K, M, N, K, _stream(G))
+    _f32(dbias)
+    _lib.lib().od_gemm_tn(dt_code(G.dtype), _p(G), _ld(G), _p(A), _ld(A), _p(dW), K, _p(dbias), M, N, K, _stream(G))
 
 
 def colsum(G, out, n_cols=None):

@@ -47,9 +47,11 @@ def test_gemm_tn_colsum(dev, dtype, M, N, K):
     Af = mk((M, lda), g, dev, dtype)
     dW0 = mk((N, K), g, dev)
     dW = dW0.clone()
-    ops.gemm_tn(Gf, Af, dW, n_cols=N, k_cols=K)
+    db = torch.ones(N, device=dev)
+    ops.gemm_tn(Gf, Af, dW, n_cols=N, k_cols=K, dbias=db)
     ref = Gf.float().cpu()[:, :N].t() @ Af.float().cpu()[:, :K] + dW0.cpu()
     assert rel_l2(dW, ref) < TOL[dtype]
+    assert rel_l2(db - 1, Gf.float().cpu()[:, :N].sum(0)) < TOL[dtype]
     out = torch.zeros(N, device=dev)
     ops.colsum(Gf, out, n_cols=N)
     assert rel_l2(out, Gf.float().cpu()[:, :N].sum(0)) < TOL[dtype]
