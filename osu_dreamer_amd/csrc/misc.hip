@@ -299,15 +299,22 @@ __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __res
         db[n] += s;
     }
 }
-// dx[b][k] (+)= sum_n dpre[b][n] W[n][k]
+// dx[b][k] (+)= sum_n dpre[b][n] W[n][k]   — block = 64 k-columns x 4 n-slices, LDS-reduced
 __global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __restrict__ W, const float* __restrict__ dpre,
                                                               float* __restrict__ dx, int accumulate, int B, int N, int K) {
+    __shared__ float red[4][64];
     const int b = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    const int kl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl;
     float s = 0.f;
-    for (int n = 0; n < N; n++) s += dpre[(size_t)b * N + n] * W[(size_t)n * K + k];
-    if (accumulate) dx[(size_t)b * K + k] += s; else dx[(size_t)b * K + k] = s;
+    if (k < K)
+        for (int n = slice; n < N; n += 4) s += dpre[(size_t)b * N + n] * W[(size_t)n * K + k];
+    red[slice][kl] = s;
+    __syncthreads();
+    if (slice == 0 && k < K) {
+        s = red[0][kl] + red[1][kl] + red[2][kl] + red[3][kl];
+        if (accumulate) dx[(size_t)b * K + k] += s; else dx[(size_t)b * K + k] = s;
+    }
 }
 
 // ------------------------------------------------------------ fp32 master weight -> packed compute copy
@@ -417,7 +424,7 @@ extern "C" int od_linear_small_bwd(const float* x, const float* W, const float* 
     if (dW || db)
         OD_LAUNCH(linear_small_dw_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (const float*)dpre, dW, db, B, N, K);
     if (dx)
-        OD_LAUNCH(linear_small_dx_kernel, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, W, (const float*)dpre, dx, accumulate_dx, B, N, K);
+        OD_LAUNCH(linear_small_dx_kernel, dim3((K + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, W, (const float*)dpre, dx, accumulate_dx, B, N, K);
     OD_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,230 @@
+"""`fit-denoiser` — the training shell around `DiffusionTrainer`.
+
+The reference drives its LightningModule with `LightningCLI` + `pytorch_lightning.Trainer`
+(osu_dreamer/scripts/fit_denoiser.py:17-32) configured by models/diffusion/model.yml:3-40.
+Lightning is not installed on the MI355X image, so this module implements exactly the subset
+that config uses, calling the same hooks in the same order:
+
+  seed_everything · precision bf16-mixed (autocast) · gradient_clip_val (global norm, fused into
+  the optimizer pass) · AdamW + LambdaLR stepped per batch · on_train_batch_end (EMA) ·
+  validation over full maps with the EMA weights · ModelCheckpoint(monitor=val/loss, mode=min,
+  save_top_k=1) · resume from --ckpt-path · log_every_n_steps · devices N (one process per GPU,
+  gradient exchange by osu_dreamer_amd.ddp.GradBucketReducer over RCCL).
+
+Checkpoints keep Lightning's layout (`state_dict`, `hyper_parameters`, `optimizer_states`,
+`lr_schedulers`, `global_step`, `epoch`) so `export-inference` (models/inference/artifact.py)
+reads them unchanged.
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+import os
+import random
+import time
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+import yaml
+
+from . import _lib
+from .data import LatentDataModule
+from .lr_schedule import LRScheduleArgs
+from .model import BackboneArgs, DiffusionModelArgs
+from .train import DiffusionTrainer
+
+DEFAULT_CONFIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "model.yml")
+
+
+def seed_everything(seed) -> int:
+    seed = 0 if seed is True else int(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return seed
+
+
+def _plain(o):
+    if dataclasses.is_dataclass(o):
+        return {k: _plain(v) for k, v in dataclasses.asdict(o).items()}
+    if isinstance(o, dict):
+        return {k: _plain(v) for k, v in o.items()}
+    return o
+
+
+class Trainer:
+    def __init__(self, max_epochs: int = -1, max_steps: int = -1, precision: str = "bf16-mixed",
+                 gradient_clip_val: Optional[float] = None, log_every_n_steps: int = 5,
+                 val_check_interval: Optional[int] = None, limit_val_batches: Optional[int] = None,
+                 default_root_dir: str = "runs/denoiser", accelerator: str = "gpu", devices: int = 1,
+                 enable_checkpointing: bool = True, **_ignored):
+        self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.precision = str(precision)
+        self.gradient_clip_val = gradient_clip_val
+        self.log_every_n_steps = log_every_n_steps
+        self.val_check_interval = val_check_interval
+        self.limit_val_batches = limit_val_batches
+        self.root = default_root_dir
+        self.enable_checkpointing = enable_checkpointing
+        self.global_step, self.epoch = 0, 0
+        self.best_val = float("inf")
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.history = []
+
+    # ------------------------------------------------------------------
+    def _autocast(self, device):
+        if self.precision.startswith("bf16"):
+            return torch.autocast(device.type, dtype=torch.bfloat16)
+        return torch.autocast(device.type, enabled=False)
+
+    def _to(self, batch, device):
+        return tuple(t.to(device, non_blocking=True) for t in batch)
+
+    def save_checkpoint(self, path, module, opt, sched):
+        ckpt = {
+            "state_dict": module.state_dict(),
+            "hyper_parameters": _plain(module.hparams_dict),
+            "optimizer_states": [opt.state_dict()],
+            "lr_schedulers": [sched.state_dict()],
+            "global_step": self.global_step, "epoch": self.epoch, "best_val": self.best_val,
+        }
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".tmp"
+        torch.save(ckpt, tmp)
+        os.replace(tmp, path)
+
+    def validate(self, module, datamodule, device):
+        sums: Dict[str, float] = {}
+        n = 0
+        for i, batch in enumerate(datamodule.val_dataloader()):
+            if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                break
+            with self._autocast(device):
+                logs = module.validation_step(self._to(batch, device), i)
+            for k, v in logs.items():
+                sums[k] = sums.get(k, 0.0) + float(v)
+            n += 1
+        return {f"val/{k}": v / max(n, 1) for k, v in sums.items()}
+
+    def fit(self, module: DiffusionTrainer, datamodule, ckpt_path: Optional[str] = None):
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.local_rank)
+            device = torch.device("cuda", self.local_rank)
+        elif _lib.loaded_path() not in (None, _lib.DEFAULT_SO):
+            device = torch.device("cpu")     # test-suite only: kernels bound to the SIMT emulator build
+        else:
+            raise RuntimeError("fit-denoiser needs an MI355X: osu_dreamer_amd has no CPU path")
+        reducer = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("nccl" if device.type == "cuda" else "gloo",
+                                        **({"device_id": device} if device.type == "cuda" else {}))
+        module.gradient_clip_val = self.gradient_clip_val
+        module.to(device)
+        cfg = module.configure_optimizers()
+        opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+        if ckpt_path:
+            ck = torch.load(ckpt_path, map_location=device, weights_only=False)
+            module.load_state_dict(ck["state_dict"])
+            opt.load_state_dict(ck["optimizer_states"][0])
+            sched.load_state_dict(ck["lr_schedulers"][0])
+            self.global_step, self.epoch = ck["global_step"], ck["epoch"]
+            self.best_val = ck.get("best_val", float("inf"))
+        if self.world > 1:
+            from .ddp import GradBucketReducer
+            reducer = GradBucketReducer(module.diffusion)
+            reducer.broadcast_parameters(0)
+        log_path = os.path.join(self.root, "metrics.jsonl")
+        if self.rank == 0:
+            os.makedirs(self.root, exist_ok=True)
+        t_last = time.time()
+        done = False
+        while not done:
+            for batch_idx, batch in enumerate(datamodule.train_dataloader()):
+                batch = self._to(batch, device)
+                opt.zero_grad()
+                with self._autocast(device):
+                    loss = module.training_step(batch, batch_idx)
+                loss.backward()
+                opt.step()
+                sched.step()
+                module.on_train_batch_end()
+                self.global_step += 1
+                if self.global_step % self.log_every_n_steps == 0 and self.rank == 0:
+                    rec = {"step": self.global_step, "epoch": self.epoch, "lr": opt.param_groups[0]["lr"],
+                           "s_per_step": (time.time() - t_last) / self.log_every_n_steps,
+                           **{k: float(v) for k, v in module._logged.items() if k.startswith("train/")}}
+                    t_last = time.time()
+                    self.history.append(rec)
+                    with open(log_path, "a") as f:
+                        f.write(json.dumps(rec) + "\n")
+                if self.val_check_interval and self.global_step % self.val_check_interval == 0:
+                    self._validate_and_checkpoint(module, datamodule, device, opt, sched)
+                if 0 < self.max_steps <= self.global_step:
+                    done = True
+                    break
+            self.epoch += 1
+            if not self.val_check_interval:
+                self._validate_and_checkpoint(module, datamodule, device, opt, sched)
+            if 0 < self.max_epochs <= self.epoch:
+                done = True
+        return self.history
+
+    def _validate_and_checkpoint(self, module, datamodule, device, opt, sched):
+        val = self.validate(module, datamodule, device)
+        if self.rank != 0:
+            return
+        self.history.append({"step": self.global_step, **val})
+        with open(os.path.join(self.root, "metrics.jsonl"), "a") as f:
+            f.write(json.dumps({"step": self.global_step, **val}) + "\n")
+        if self.enable_checkpointing and val.get("val/loss", float("inf")) < self.best_val:
+            self.best_val = val["val/loss"]
+            self.save_checkpoint(os.path.join(self.root, "checkpoints", "best.ckpt"), module, opt, sched)
+
+
+def build_from_config(cfg: Dict[str, Any]):
+    m = dict(cfg["model"])
+    da = dict(m["diffusion_args"])
+    da["backbone_args"] = BackboneArgs(**da["backbone_args"])
+    m["diffusion_args"] = DiffusionModelArgs(**da)
+    m["schedule_args"] = LRScheduleArgs(**m["schedule_args"])
+    module = DiffusionTrainer(**m)
+    t = dict(cfg.get("trainer", {}))
+    for k in ("callbacks", "logger", "accumulate_grad_batches", "enable_progress_bar", "enable_model_summary", "benchmark"):
+        t.pop(k, None)
+    return module, Trainer(**t)
+
+
+def fit_denoiser(config: str = DEFAULT_CONFIG, ckpt_path: Optional[str] = None, **overrides):
+    """begin a training run for the diffusion model (reference: scripts/fit_denoiser.py:17-32)."""
+    with open(config) as f:
+        cfg = yaml.safe_load(f)
+    for k, v in overrides.items():          # e.g. data__data_path="..."
+        sec, key = k.split("__")
+        cfg.setdefault(sec, {})[key] = v
+    if cfg.get("seed_everything") not in (None, False):
+        seed_everything(cfg["seed_everything"])
+    module, trainer = build_from_config(cfg)
+    data = LatentDataModule(**cfg["data"], rank=trainer.rank, world_size=trainer.world)
+    trainer.fit(module, data, ckpt_path=ckpt_path)
+    return module, trainer
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="osu_dreamer_amd")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    f = sub.add_parser("fit-denoiser", help="begin a training run for the diffusion model")
+    f.add_argument("-c", "--config", default=DEFAULT_CONFIG)
+    f.add_argument("--ckpt-path", default=None)
+    a = ap.parse_args(argv)
+    if a.cmd == "fit-denoiser":
+        fit_denoiser(a.config, a.ckpt_path)
+
+
+if __name__ == "__main__":
+    main()
