@@ -272,6 +272,9 @@ inline s16x4_t ds_read_tr16_b64(const unsigned short* p) {
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4_f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define OD_LAUNCH(kern, grid, block, smem, stream, ...) \
     emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); })
 #define OD_LAUNCH_DYN(kern, grid, block, smem, stream, ...) \
