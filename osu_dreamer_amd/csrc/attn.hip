@@ -52,6 +52,21 @@ struct Stage {
             *(u32x4*)(t + tile_off<ROWB>(row, ch * 16)) = r[i];
         }
     }
+    // LDS-DMA of the same row-major swizzled image (no VGPRs, no ds_write): the block's 4 waves each
+    // stream 1 KiB pieces = (1024 / ROWB) tile rows; the swizzle is applied to the source column.
+    static __device__ __forceinline__ void dma_rowmajor(const T* base, int ld, int row0, int nrows, unsigned char* t) {
+        constexpr int RPP = 1024 / ROWB;                   // rows per piece
+        constexpr int NP = BYTES / 1024 / 4;               // pieces per wave
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int piece = wave * NP + i;
+            const int row = piece * RPP + lane / CPR;
+            const int slot = (lane % CPR) ^ (row & (CPR - 1));
+            int gr = row0 + row; gr = gr < nrows ? gr : nrows - 1;
+            od_glds16(base + (size_t)gr * ld + slot * EPC, t + piece * 1024 + lane * 16);
+        }
+    }
     // element (row, col) -> transposed tile row `col`, position `row`
     __device__ __forceinline__ void store_transposed(unsigned char* t) const {
 #pragma unroll
@@ -128,14 +143,22 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
         sk.store_rowmajor(base);
         if constexpr (St::TR) sv.store_rowmajor(base + St::BYTES); else sv.store_transposed(base + St::BYTES);
     };
-    sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L);
-    lstore(smem);
+    // bf16: K/V tiles go global -> LDS by LDS-DMA; f32 (V must be transposed) stages through registers
+    auto dma = [&](int kt, unsigned char* base) {
+        St::dma_rowmajor(kb, ldk, kt * 64, L, base);
+        St::dma_rowmajor(vb, ldv, kt * 64, L, base + St::BYTES);
+    };
+    if constexpr (St::TR) dma(0, smem);
+    else { sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L); lstore(smem); }
     __syncthreads();
     auto tile = [&](int kt, auto masked_t) {
         constexpr bool MASKED = decltype(masked_t)::value;
         const unsigned char* tK = smem + (kt & 1) * 2 * St::BYTES;
         const unsigned char* tV = tK + St::BYTES;
-        if (kt + 1 < nkt) { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
+        if (kt + 1 < nkt) {
+            if constexpr (St::TR) dma(kt + 1, smem + ((kt + 1) & 1) * 2 * St::BYTES);
+            else { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
+        }
 
         // S^T tiles: rows = keys (4 tiles of 16), cols = queries
         f32x4 sacc[2][4];
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
 #pragma unroll
                 for (int qi = 0; qi < 2; qi++) oacc[qi][dt] = od_mma(fv, fp[qi][u], oacc[qi][dt]);
             }
-        if (kt + 1 < nkt) lstore(smem + ((kt + 1) & 1) * 2 * St::BYTES);
+        if constexpr (!St::TR) { if (kt + 1 < nkt) lstore(smem + ((kt + 1) & 1) * 2 * St::BYTES); }
         __syncthreads();
     };
     const int nfull = L / 64;
@@ -308,14 +331,33 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
         float* sl = (float*)(st + (2 + 2 * St::NT) * St::BYTES);
         if (threadIdx.x < 64) { sl[threadIdx.x] = r_lse * LOG2E; sl[64 + threadIdx.x] = r_del; }
     };
-    gload(0);
-    lstore(smem);
+    // bf16: Q/dO tiles by LDS-DMA into the other stage at the top of the iteration; lse/delta by registers
+    auto gload_small = [&](int qt) {
+        if (threadIdx.x < 64) {
+            const int row = qt * 64 + threadIdx.x;
+            r_lse = row < L ? lseb[row] : 0.f;
+            r_del = row < L ? delb[row] : 0.f;
+        }
+    };
+    auto lstore_small = [&](unsigned char* st) {
+        float* sl = (float*)(st + (2 + 2 * St::NT) * St::BYTES);
+        if (threadIdx.x < 64) { sl[threadIdx.x] = r_lse * LOG2E; sl[64 + threadIdx.x] = r_del; }
+    };
+    auto dma = [&](int qt, unsigned char* st) {
+        St::dma_rowmajor(qb, ldq, qt * 64, L, st);
+        St::dma_rowmajor(dob, lddo, qt * 64, L, st + St::BYTES);
+    };
+    if constexpr (St::TR) { dma(0, smem); gload_small(0); lstore_small(smem); }
+    else { gload(0); lstore(smem); }
     __syncthreads();
     int cur = 0;
     const bool kragged = ktile * KB + KB > L;
     auto tile = [&](int qt, auto masked_t) {
         constexpr bool MASKED = decltype(masked_t)::value;
-        if (qt + 1 < nqt) gload(qt + 1);
+        if (qt + 1 < nqt) {
+            if constexpr (St::TR) { dma(qt + 1, smem + (cur ^ 1) * STAGE); gload_small(qt + 1); }
+            else gload(qt + 1);
+        }
         const unsigned char* st = smem + cur * STAGE;
         const unsigned char* tQ = st;
         const unsigned char* tO = st + St::BYTES;
@@ -370,7 +412,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
                 }
             }
         if (NSTAGE == 1) __syncthreads();
-        if (qt + 1 < nqt) lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0));
+        if (qt + 1 < nqt) {
+            if constexpr (St::TR) lstore_small(smem + (cur ^ 1) * STAGE);
+            else lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0));
+        }
         __syncthreads();
         if (NSTAGE == 2) cur ^= 1;
     };
@@ -441,13 +486,20 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
         sk.store_rowmajor(st); sv.store_rowmajor(st + St::BYTES);
         if constexpr (!St::TR) sk.store_transposed(st + 2 * St::BYTES);
     };
-    sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L);
-    lstore(smem);
+    auto dma = [&](int kt, unsigned char* st) {
+        St::dma_rowmajor(kb, ldk, kt * 64, L, st);
+        St::dma_rowmajor(vb, ldv, kt * 64, L, st + St::BYTES);
+    };
+    if constexpr (St::TR) dma(0, smem);
+    else { sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L); lstore(smem); }
     __syncthreads();
     int cur = 0;
     auto tile = [&](int kt, auto masked_t) {
         constexpr bool MASKED = decltype(masked_t)::value;
-        if (kt + 1 < nkt) { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
+        if (kt + 1 < nkt) {
+            if constexpr (St::TR) dma(kt + 1, smem + (cur ^ 1) * STAGE);
+            else { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
+        }
         const unsigned char* st = smem + cur * STAGE;
         const unsigned char* tK = st;
         const unsigned char* tV = st + St::BYTES;
@@ -489,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
                 for (int qi = 0; qi < NQ; qi++) dqacc[qi][dt] = od_mma(fkt, fds[qi][u], dqacc[qi][dt]);
             }
         if (NSTAGE == 1) __syncthreads();
-        if (kt + 1 < nkt) lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0));
+        if constexpr (!St::TR) { if (kt + 1 < nkt) lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0)); }
         __syncthreads();
         if (NSTAGE == 2) cur ^= 1;
     };

@@ -65,7 +65,7 @@ __device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int& tm,
     return tm < tiles_m;
 }
 
-template <class T, int EPI>
+template <class T, int EPI, bool DMA>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                       const float* __restrict__ bias, T* __restrict__ C, int ldc,
                                                       int M, int N, int K, int accumulate) {
@@ -115,6 +115,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         }
     };
 
+    if constexpr (DMA) {
+        // LDS-DMA staging (requires K % BK == 0): wave w streams 1 KiB pieces = 8 tile rows x 128 B; the
+        // XOR swizzle is applied to the SOURCE column so the LDS image is the same one the reads expect.
+        auto dma = [&](int kt, int buf) {
+            unsigned char* sA = smem + buf * STAGE_BYTES;
+            unsigned char* sB = sA + 16384;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = (wave * 4 + i) * 8 + (lane >> 3);
+                const int slot = (lane & 7) ^ (row & 7);
+                const int k = kt * BK + slot * CH;
+                int ar = m0 + row; ar = ar < M ? ar : M - 1;
+                int br = n0 + row; br = br < N ? br : N - 1;
+                od_glds16(A + (size_t)ar * lda + k, sA + (wave * 4 + i) * 1024 + lane * 16);
+                od_glds16(W + (size_t)br * ldw + k, sB + (wave * 4 + i) * 1024 + lane * 16);
+            }
+        };
+        dma(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+            compute_stage<T>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+            __syncthreads();
+        }
+    } else {
     gload(0);
     lstore(0);
     __syncthreads();
@@ -124,6 +150,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         compute_stage<T>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
+    }
     }
 
     // epilogue: accumulators -> LDS (f32 [128][128]) -> coalesced row stores
@@ -182,6 +209,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 // transpose read): the slab is transposed while it is written to LDS.
 // Blocks of k-tile 0 also accumulate the column sums of G (the bias gradient) from the registers
 // they stage, so G is not read a second time.
+// 256-byte-row tile addressing for the TN slabs: XOR at 32-byte granularity (slot PAIRS), because a
+// transpose read touches two adjacent 16-byte slots of 8 different rows per 32-lane group.
+__device__ __forceinline__ int tn_off(int row, int byte) {
+    return row * 256 + ((((byte >> 5)) ^ (row & 7)) << 5) + (byte & 31);
+}
+__device__ __forceinline__ void tn_frag(od_frag<bf16_t>& f, const unsigned char* t, int c0, int x, int u, int g) {
+    const int cb = (c0 + 4 * (x & 3)) * 2, rr = 32 * u + 4 * g + (x >> 2);
+    const s16x4 a = od_lds_tr_read((const bf16_t*)(t + tn_off(rr, cb)));
+    const s16x4 b = od_lds_tr_read((const bf16_t*)(t + tn_off(rr + 16, cb)));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+__device__ __forceinline__ void tn_frag(od_frag<float>&, const unsigned char*, int, int, int, int) {}
+
 template <class T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ A, int lda,
                                                       float* __restrict__ dW, int lddw, float* __restrict__ dbias,
@@ -210,40 +251,89 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
 
     constexpr int CPR = 128 / CH;              // 16-byte chunks per slab row (16 bf16 / 32 f32)
     constexpr int NCH = BR * CPR / 256;        // chunks per thread per operand (4)
-    u32x4 rg[NCH], ra[NCH];
-    float bsum[CH];
-#pragma unroll
-    for (int e = 0; e < CH; e++) bsum[e] = 0.f;
     const int nslab = (me - mb + BR - 1) / BR;
 
-    auto gload = [&](int st) {
+    if constexpr (TR) {
+        // ---- bf16: LDS-DMA of row-major slabs (out-of-range rows / columns read a global zero), MFMA
+        //      fragments by transpose reads.  The bias gradient is summed from the staged G slab in LDS.
+        auto dma = [&](int st, int buf) {
+            unsigned char* sA = smem + buf * STAGE_BYTES;   // G slab [64 m][128 n]
+            unsigned char* sB = sA + 16384;                  // A slab [64 m][128 k]
 #pragma unroll
-        for (int i = 0; i < NCH; i++) {
-            const int c = tid + 256 * i, r = c / CPR, cc = (c % CPR) * CH;
-            const int m = mb + st * BR + r;
-            const bool mv = m < me;
-            rg[i] = (mv && n0 + cc < N) ? *(const u32x4*)(G + (size_t)m * ldg + n0 + cc) : (u32x4)(0u);
-            ra[i] = (mv && k0 + cc < K) ? *(const u32x4*)(A + (size_t)m * lda + k0 + cc) : (u32x4)(0u);
+            for (int i = 0; i < 4; i++) {
+                const int piece = wave * 4 + i;              // 1 KiB = 4 rows x 256 B
+                const int r = piece * 4 + (lane >> 4);
+                const int pos = lane & 15;                    // 16-byte position within the LDS row
+                const int slot = ((((pos >> 1) ^ (r & 7)) << 1) | (pos & 1));   // logical column chunk stored there
+                const int cc = slot * CH;
+                const int m = mb + st * BR + r;
+                const bool mv = m < me;
+                const void* gs = (mv && n0 + cc < N) ? (const void*)(G + (size_t)m * ldg + n0 + cc) : (const void*)od_zero16;
+                const void* as = (mv && k0 + cc < K) ? (const void*)(A + (size_t)m * lda + k0 + cc) : (const void*)od_zero16;
+                od_glds16(gs, sA + piece * 1024 + lane * 16);
+                od_glds16(as, sB + piece * 1024 + lane * 16);
+            }
+        };
+        float bsum = 0.f;                                    // thread t < 128 owns column n0 + t
+        dma(0, 0);
+        __syncthreads();
+        const int x = lane & 15, g = lane >> 4;
+        for (int st = 0; st < nslab; st++) {
+            const int buf = st & 1;
+            if (st + 1 < nslab) dma(st + 1, buf ^ 1);
+            const unsigned char* sA = smem + buf * STAGE_BYTES;
+            const unsigned char* sB = sA + 16384;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                od_frag<T> fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) tn_frag(fa[i], sA, wm * 64 + i * 16, x, u, g);
+#pragma unroll
+                for (int j = 0; j < 4; j++) tn_frag(fb[j], sB, wn * 64 + j * 16, x, u, g);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] = od_mma(fa[i], fb[j], acc[i][j]);
+            }
+            if (do_bias) {
+                const int col = tid & 127, half = tid >> 7;
+#pragma unroll 8
+                for (int r = 0; r < 32; r++)
+                    bsum += od_bf2f(*(const bf16_t*)(sA + tn_off(half * 32 + r, col * 2)));
+            }
+            __syncthreads();
         }
-        if (do_bias) {
+        if (do_bias) atomicAdd(&sred[tid & 127], bsum);
+    } else {
+        // ---- f32: register staging, transposing while writing to LDS ([col][m], 128-byte rows)
+        u32x4 rg[NCH], ra[NCH];
+        float bsum[CH];
+#pragma unroll
+        for (int e = 0; e < CH; e++) bsum[e] = 0.f;
+        auto gload = [&](int st) {
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
-                const T* pg = (const T*)&rg[i];
-#pragma unroll
-                for (int e = 0; e < CH; e++) bsum[e] += od_t<T>::ld(pg + e);
+                const int c = tid + 256 * i, r = c / CPR, cc = (c % CPR) * CH;
+                const int m = mb + st * BR + r;
+                const bool mv = m < me;
+                rg[i] = (mv && n0 + cc < N) ? *(const u32x4*)(G + (size_t)m * ldg + n0 + cc) : (u32x4)(0u);
+                ra[i] = (mv && k0 + cc < K) ? *(const u32x4*)(A + (size_t)m * lda + k0 + cc) : (u32x4)(0u);
             }
-        }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* sA = smem + buf * STAGE_BYTES;   // G slab
-        unsigned char* sB = sA + 16384;                  // A slab
+            if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < NCH; i++) {
-            const int c = tid + 256 * i, r = c / CPR, cc = (c % CPR) * CH;
-            if constexpr (TR) {                          // row-major [m][128], 256-byte rows
-                *(u32x4*)(sA + tile_off<256>(r, cc * 2)) = rg[i];
-                *(u32x4*)(sB + tile_off<256>(r, cc * 2)) = ra[i];
-            } else {                                     // transposed [col][m], 128-byte rows
+                for (int i = 0; i < NCH; i++) {
+                    const T* pg = (const T*)&rg[i];
+#pragma unroll
+                    for (int e = 0; e < CH; e++) bsum[e] += od_t<T>::ld(pg + e);
+                }
+            }
+        };
+        auto lstore = [&](int buf) {
+            unsigned char* sA = smem + buf * STAGE_BYTES;
+            unsigned char* sB = sA + 16384;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const int c = tid + 256 * i, r = c / CPR, cc = (c % CPR) * CH;
                 const T* pg = (const T*)&rg[i];
                 const T* pa = (const T*)&ra[i];
 #pragma unroll
@@ -252,54 +342,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
                     *(T*)(sB + tile_off<128>(cc + e, r * (int)sizeof(T))) = pa[e];
                 }
             }
-        }
-    };
-    auto compute = [&](int buf) {
-        const unsigned char* sA = smem + buf * STAGE_BYTES;
-        const unsigned char* sB = sA + 16384;
-        if constexpr (TR) {
-            const int x = lane & 15, g = lane >> 4;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                od_frag<T> fa[4], fb[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) frag_cols<256, 0>(fa[i], sA, sA, wm * 64 + i * 16, x, u, g);
-#pragma unroll
-                for (int j = 0; j < 4; j++) frag_cols<256, 0>(fb[j], sB, sB, wn * 64 + j * 16, x, u, g);
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i][j] = od_mma(fa[i], fb[j], acc[i][j]);
-            }
-        } else {
-            compute_stage<T>(sA, sB, wm, wn, lane, acc);
-        }
-    };
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int st = 0; st < nslab; st++) {
-        const int buf = st & 1;
-        if (st + 1 < nslab) gload(st + 1);
-        compute(buf);
-        if (st + 1 < nslab) lstore(buf ^ 1);
+        };
+        gload(0);
+        lstore(0);
         __syncthreads();
+        for (int st = 0; st < nslab; st++) {
+            const int buf = st & 1;
+            if (st + 1 < nslab) gload(st + 1);
+            compute_stage<T>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+            if (st + 1 < nslab) lstore(buf ^ 1);
+            __syncthreads();
+        }
+        if (do_bias) {
+            const int cc = (tid % CPR) * CH;
+#pragma unroll
+            for (int e = 0; e < CH; e++) atomicAdd(&sred[cc + e], bsum[e]);
+        }
     }
-    const int col = lane & 15, g = lane >> 4;
+    const int col = lane & 15, g2 = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int n = n0 + wm * 64 + i * 16 + g * 4 + r, k = k0 + wn * 64 + j * 16 + col;
+                const int n = n0 + wm * 64 + i * 16 + g2 * 4 + r, k = k0 + wn * 64 + j * 16 + col;
                 if (n < N && k < K) atomicAdd(dW + (size_t)n * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
-        const int cc = (tid % CPR) * CH;
-#pragma unroll
-        for (int e = 0; e < CH; e++) atomicAdd(&sred[cc + e], bsum[e]);
         __syncthreads();
         if (tid < 128 && n0 + tid < N) atomicAdd(dbias + n0 + tid, sred[tid]);
     }
@@ -323,10 +393,14 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
               int accumulate, hipStream_t st) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-    if (epi == OD_EPI_SILU)
-        OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_SILU>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
-    else
-        OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_NONE>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+    const bool dma = (K % (128 / (int)sizeof(T))) == 0;
+    if (epi == OD_EPI_SILU) {
+        if (dma) OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_SILU, true>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+        else OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_SILU, false>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+    } else {
+        if (dma) OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_NONE, true>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+        else OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_NONE, false>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+    }
     OD_CHECK_LAUNCH();
     return 0;
 }

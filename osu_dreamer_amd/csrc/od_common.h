@@ -167,6 +167,21 @@ __device__ __forceinline__ f32x4 od_mma(const od_frag<float>& a, const od_frag<f
     return c;
 }
 
+// 16 zero bytes in global memory: the source of LDS-DMA lanes that fall outside a matrix
+static __device__ __attribute__((aligned(16))) unsigned char od_zero16[16];
+
+// LDS-DMA: 16 bytes per lane straight from global memory into LDS, no VGPR round trip and no
+// ds_write.  The hardware writes lane i's 16 bytes at (wave-uniform LDS base) + 16*i, so `lds` must be
+// lane 0's destination + 16*lane; the SOURCE address is free per lane (swizzles go there).
+#if defined(OD_EMU)
+__device__ __forceinline__ void od_glds16(const void* g, void* lds) { emu::global_load_lds16(g, lds); }
+#else
+__device__ __forceinline__ void od_glds16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+#endif
+
 #define OD_CHECK_LAUNCH()                                \
     do {                                                 \
         hipError_t e__ = hipGetLastError();              \

@@ -268,6 +268,22 @@ inline s16x4_t ds_read_tr16_b64(const unsigned short* p) {
 }
 }  // namespace emu
 
+namespace emu {
+// global_load_lds_dwordx4: lane i's 16 bytes land at (lane 0's LDS pointer) + 16*i
+inline void global_load_lds16(const void* g, void* lds) {
+    State& s = S();
+    int w = wave_id(), l = lane_id();
+    memcpy(s.xbuf[w][l], &lds, sizeof(lds));
+    wave_barrier();
+    int first = 0;
+    for (int i = 0; i < 64; i++) if ((w * 64 + i) < s.nthreads && !s.fibers[w * 64 + i].done) { first = i; break; }
+    unsigned char* base;
+    memcpy(&base, s.xbuf[w][first], sizeof(base));
+    memcpy(base + 16 * (l - first), g, 16);
+    wave_barrier();
+}
+}  // namespace emu
+
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4_f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
