@@ -109,10 +109,19 @@ def roofline_of_dominant_kernel(tr, B, L):
     # od_flash_attn_bwd = delta + dK/dV kernel (4 passes) + dQ kernel (3 passes); fwd = 2 passes
     ach_bwd = 7 * unit / t_bwd / 1e12
     ach_fwd = 2 * unit / t_fwd / 1e12
+    # HBM bytes per launch are PMC measurements from a separate rocprofv3 pass (FETCH_SIZE x2 + WRITE_SIZE,
+    # profiles/r01_traffic.json); they cannot be collected from inside this process.
+    traffic = None
+    try:
+        tr_ = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
+        if (B, L) == (32, 8192):
+            traffic = tr_["od_flash_attn_bwd"]["read_bytes"] + tr_["od_flash_attn_bwd"]["write_bytes"]
+    except Exception:
+        pass
     return {
         "bound": "mfma", "kernel": "flash_bwd_dkv_kernel+flash_bwd_dq_kernel (od_flash_attn_bwd)",
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
         "ms_per_launch": round(t_bwd * 1e3, 3),
         "also": {"od_flash_attn_fwd": {"achieved": round(ach_fwd, 1), "frac": round(ach_fwd / PEAK_BF16_TFLOPS, 4),
                                        "ms_per_launch": round(t_fwd * 1e3, 3)}},
