@@ -128,7 +128,7 @@ def roofline_of_dominant_kernel(tr, B, L):
     }
 
 
-def cpu_baseline(L_cpu=1024):
+def cpu_baseline(L_cpu=2048):
     """The CPU oracle (a port of the reference path, pinned by tests/golden) timed on this box's
     host cores on a bounded sample: ONE fp32 training step at batch 1 x L_cpu frames, scaled to the
     metric's unit by frames (a bench step is 32 x 8192 frames)."""
