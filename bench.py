@@ -204,13 +204,16 @@ def main():
     from osu_dreamer_amd import _lib
     _lib.lib()                                   # fail loudly if the HIP library is missing
     reducer = None
-    if world > 1:
+    ddp = world > 1 or os.environ.get("OD_FORCE_DDP") == "1"      # OD_FORCE_DDP: exercise the RCCL path on one GPU
+    if ddp:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
     B, L = args.batch, args.frames
     tr = make_trainer(device, seed=1234)
     tr.diffusion.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if world > 1:
+    if ddp:
         from osu_dreamer_amd.ddp import GradBucketReducer
         reducer = GradBucketReducer(tr.diffusion)
         reducer.broadcast_parameters(0)
@@ -228,7 +231,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if ddp:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -241,7 +244,7 @@ def main():
         loss = step(args.warmup + i)
     barrier()
     dt = time.time() - t0
-    if world > 1:
+    if ddp:
         import torch.distributed as dist
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -277,10 +280,15 @@ def main():
             line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
             line["sampler"] = sampler_bench(device)
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    else:
+        line = None
+    if ddp:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()      # RCCL prints its banner here: keep the JSON the LAST line
+    if line is not None:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
