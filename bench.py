@@ -183,6 +183,28 @@ def sampler_bench(device):
     return {"workload": "50-step sampler, B=4, L=1115, audio batch 1 (broadcast), hipGraph", **out}
 
 
+def forward_target_shape(tr, device, B=64, L=8192):
+    """north_star's target shape: denoiser FORWARD at batch 64 x 8192 frames, bf16.  Reports the binding
+    (MFMA) fraction and, because the target was phrased against HBM, the HBM fraction of the algorithmic
+    bytes as well (87,314 elements/frame)."""
+    h, z, s, _ = synthetic_batch(B, L, device, seed=99)
+    m = tr.diffusion
+    with torch.no_grad():
+        m(h, s, z)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(2):
+            m(h, s, z)
+        torch.cuda.synchronize()
+    dt = (time.time() - t0) / 2
+    fl = flops_forward(B * L, L)
+    by = 87_314 * 2.0 * B * L
+    return {"workload": f"denoiser forward, batch {B} x {L} frames, bf16", "ms": round(dt * 1e3, 1),
+            "tflops": round(fl / dt / 1e12, 1), "mfma_frac": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "algorithmic_gb": round(by / 1e9, 1), "hbm_frac_of_algorithmic_bytes": round(by / dt / 1e9 / PEAK_HBM_GBS, 4),
+            "frames_per_s": round(B * L / dt, 0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +300,7 @@ def main():
         }
         if not args.no_extras and world == 1:
             line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
+            line["forward_64x8192"] = forward_target_shape(tr, device)
             line["sampler"] = sampler_bench(device)
             line["cpu_baseline"] = cpu_baseline()
     else:
