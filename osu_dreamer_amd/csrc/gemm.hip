@@ -15,6 +15,10 @@
 
 namespace {
 
+#ifndef OD_GEMM_BIG_MIN_M
+#define OD_GEMM_BIG_MIN_M 32768   // rows from which the 256x256 kernels are used
+#endif
+
 constexpr int BM = 128, BN = 128;
 constexpr int STAGE_BYTES = 32768;  // A 16 KiB + B 16 KiB
 
@@ -209,6 +213,110 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 // transpose read): the slab is transposed while it is written to LDS.
 // Blocks of k-tile 0 also accumulate the column sums of G (the bias gradient) from the registers
 // they stage, so G is not read a second time.
+// ---- NT, large-M variant: 256x256 block tile, 8 waves (2 x 4) each owning 128 (m) x 64 (n) ----------
+// Why: a 1-KiB LDS-DMA piece costs the issuing wave ~100+ cycles; at 128x128 a wave issues 8 pieces per
+// 32 MFMAs.  Doubling both tile edges halves pieces per MFMA (8 per 64) and LDS fragment reads per MFMA
+// (24 per 64 instead of 16 per 32).  128 KiB of dynamic LDS (2 stages x (A 32 KiB + W 32 KiB)), one
+// workgroup per CU.  The MFMA is issued as (W rows) x (A rows)^T with the W-row permutation
+//   pair p, half h, tile-row rho -> n = 32p + 8(rho>>2) + 4h + (rho&3)
+// so a lane ends up holding 8 consecutive output columns of one output row: the epilogue is one 16-byte
+// store per tile pair straight from the accumulators (no LDS round trip).
+template <class T, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                             const float* __restrict__ bias, T* __restrict__ C, int ldc,
+                                                             int M, int N, int K, int accumulate) {
+    constexpr int TM = 256, TN = 256;
+    constexpr int BK = 128 / (int)sizeof(T);
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int SLABS = BK / 32;
+    constexpr int STG = 65536;                 // bytes per stage: A 32 KiB then W 32 KiB
+    OD_DYN_SMEM(smem);
+    const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
+    int tm, tn;
+    if (!tile_of_block(tiles_m, tiles_n, tm, tn)) return;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int x = lane & 15, g = lane >> 4;
+
+    f32x4 acc[4][8];           // [n tile i (pair i>>1, half i&1)][m tile j]
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4)(0.f);
+    const int nk = K / BK;
+
+    auto dma = [&](int kt, int buf) {
+        unsigned char* st = smem + buf * STG;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int piece = wave * 8 + i;                 // 0..31 -> A rows, 32..63 -> W rows
+            const bool isw = piece >= 32;
+            const int row = (piece & 31) * 8 + (lane >> 3);
+            const int slot = (lane & 7) ^ (row & 7);
+            const int k = kt * BK + slot * CH;
+            int gr = (isw ? n0 : m0) + row;
+            const int lim = isw ? N : M;
+            gr = gr < lim ? gr : lim - 1;
+            const T* src = isw ? (W + (size_t)gr * ldw + k) : (A + (size_t)gr * lda + k);
+            od_glds16(src, st + piece * 1024 + lane * 16);
+        }
+    };
+    auto wrow = [&](int i) { return wn * 64 + 32 * (i >> 1) + 8 * (x >> 2) + 4 * (i & 1) + (x & 3); };
+
+    dma(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+        const unsigned char* sA = smem + buf * STG;
+        const unsigned char* sW = sA + 32768;
+#pragma unroll
+        for (int sl = 0; sl < SLABS; sl++) {
+            od_frag<T> fw[4], fa[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) frag_from_lds<T>(fw[i], sW, wrow(i), sl, g);
+#pragma unroll
+            for (int j = 0; j < 8; j++) frag_from_lds<T>(fa[j], sA, wm * 128 + j * 16 + x, sl, g);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[i][j] = od_mma(fw[i], fa[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    // lane (x, g): rows m0 + wm*128 + 16j + x, columns n0 + wn*64 + 32p + 8g .. +7
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int gm = m0 + wm * 128 + j * 16 + x;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int gn = n0 + wn * 64 + 32 * p + 8 * g;
+            if (gn >= N) continue;                          // N % 8 == 0 is required by the launcher
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { v[r] = acc[2 * p][j][r]; v[4 + r] = acc[2 * p + 1][j][r]; }
+            T* dst = C + (size_t)gm * ldc + gn;
+            if (bias) {
+                float bv[8]; od_ld8(bias + gn, bv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] += bv[e];
+            }
+            if (EPI == OD_EPI_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = od_silu(v[e]);
+            }
+            if (accumulate) {
+                float o[8]; od_ld8(dst, o);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] += o[e];
+            }
+            od_st8(dst, v);
+        }
+    }
+}
+
 // 256-byte-row tile addressing for the TN slabs: XOR at 32-byte granularity (slot PAIRS), because a
 // transpose read touches two adjacent 16-byte slots of 8 different rows per 32-lane group.
 __device__ __forceinline__ int tn_off(int row, int byte) {
@@ -375,6 +483,105 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
     }
 }
 
+// ---- TN, large variant (bf16): 256 (n) x 256 (k) output tile, 8 waves (2 x 4) each 128 x 64, reduction
+// slabs of 64 rows staged row-major by LDS-DMA (512-byte rows, XOR swizzle at 32-byte granularity over
+// the row's 16 slot pairs), fragments by transpose reads.  Same motivation as gemm_nt_big_kernel.
+__device__ __forceinline__ int tn512_off(int row, int byte) {
+    return row * 512 + ((((byte >> 5)) ^ (row & 15)) << 5) + (byte & 31);
+}
+__device__ __forceinline__ void tn512_frag(od_frag<bf16_t>& f, const unsigned char* t, int c0, int x, int u, int g) {
+    const int cb = (c0 + 4 * (x & 3)) * 2, rr = 32 * u + 4 * g + (x >> 2);
+    const s16x4 a = od_lds_tr_read((const bf16_t*)(t + tn512_off(rr, cb)));
+    const s16x4 b = od_lds_tr_read((const bf16_t*)(t + tn512_off(rr + 16, cb)));
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+__global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A, int lda,
+                                                             float* __restrict__ dW, int lddw, float* __restrict__ dbias,
+                                                             int M, int N, int K, int m_per_block) {
+    constexpr int STG = 65536;                 // G slab [64][256] 32 KiB + A slab [64][256] 32 KiB
+    OD_DYN_SMEM(smem);
+    float* sred = (float*)(smem + 2 * STG);    // 256 floats
+    const int tiles_n = (N + 255) / 256, tiles_k = (K + 255) / 256;
+    const int tile = blockIdx.x % (tiles_n * tiles_k), split = blockIdx.x / (tiles_n * tiles_k);
+    const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
+    const int mb = split * m_per_block;
+    int me = mb + m_per_block; me = me < M ? me : M;
+    if (mb >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int x = lane & 15, g = lane >> 4;
+    const bool do_bias = dbias != nullptr && (tile % tiles_k) == 0;
+    if (tid < 256) sred[tid] = 0.f;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4)(0.f);
+    const int nslab = (me - mb + 63) / 64;
+
+    auto dma = [&](int st, int buf) {
+        unsigned char* base = smem + buf * STG;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int piece = wave * 8 + i;                  // 0..31 G slab, 32..63 A slab; 2 rows per piece
+            const bool isa = piece >= 32;
+            const int r = (piece & 31) * 2 + (lane >> 5);
+            const int pos = lane & 31;                        // 16-byte position within the 512-byte LDS row
+            const int slot = ((((pos >> 1) ^ (r & 15)) << 1) | (pos & 1));
+            const int cc = slot * 8;
+            const int m = mb + st * 64 + r;
+            const bool mv = m < me;
+            const void* src;
+            if (isa) src = (mv && k0 + cc < K) ? (const void*)(A + (size_t)m * lda + k0 + cc) : (const void*)od_zero16;
+            else src = (mv && n0 + cc < N) ? (const void*)(G + (size_t)m * ldg + n0 + cc) : (const void*)od_zero16;
+            od_glds16(src, base + piece * 1024 + lane * 16);
+        }
+    };
+    float bsum = 0.f;
+    dma(0, 0);
+    __syncthreads();
+    for (int st = 0; st < nslab; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nslab) dma(st + 1, buf ^ 1);
+        const unsigned char* sG = smem + buf * STG;
+        const unsigned char* sA = sG + 32768;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            od_frag<bf16_t> fa[8], fb[4];
+#pragma unroll
+            for (int i = 0; i < 8; i++) tn512_frag(fa[i], sG, wm * 128 + i * 16, x, u, g);
+#pragma unroll
+            for (int j = 0; j < 4; j++) tn512_frag(fb[j], sA, wn * 64 + j * 16, x, u, g);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = od_mma(fa[i], fb[j], acc[i][j]);
+        }
+        if (do_bias) {
+            const int col = tid & 255, half = tid >> 8;
+#pragma unroll 8
+            for (int r = 0; r < 32; r++) bsum += od_bf2f(*(const bf16_t*)(sG + tn512_off(half * 32 + r, col * 2)));
+        }
+        __syncthreads();
+    }
+    if (do_bias) atomicAdd(&sred[tid & 255], bsum);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + wm * 128 + i * 16 + g * 4 + r, k = k0 + wn * 64 + j * 16 + x;
+                if (n < N && k < K) atomicAdd(dW + (size_t)n * lddw + k, acc[i][j][r]);
+            }
+    if (do_bias) {
+        __syncthreads();
+        if (tid < 256 && n0 + tid < N) atomicAdd(dbias + n0 + tid, sred[tid]);
+    }
+}
+
 // column sums (bias gradients): out[n] += sum_m G[m][n]
 template <class T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ G, int ldg, float* __restrict__ out, int M, int N,
@@ -394,6 +601,16 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const bool dma = (K % (128 / (int)sizeof(T))) == 0;
+    if (dma && M >= OD_GEMM_BIG_MIN_M && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
+        const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256;
+        const int grid2 = ((tm2 + 7) / 8) * 8 * tn2;
+        if (epi == OD_EPI_SILU)
+            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_SILU>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+        else
+            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_NONE>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     if (epi == OD_EPI_SILU) {
         if (dma) OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_SILU, true>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
         else OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_SILU, false>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
@@ -408,6 +625,19 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
 template <class T>
 int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, float* dbias, int M, int N, int K, hipStream_t st) {
     constexpr int BR = 128 / (int)sizeof(T);
+    if constexpr (sizeof(T) == 2) {
+        const int tiles2 = ((N + 255) / 256) * ((K + 255) / 256);
+        // few output tiles => many M-splits => the fp32 atomics of the epilogue dominate: stay on 128x128 there
+        if (M >= OD_GEMM_BIG_MIN_M && N >= 256 && K >= 256 && (tiles2 >= 10 || OD_GEMM_BIG_MIN_M < 32768)) {
+            int sp = (768 + tiles2 - 1) / tiles2;             // ~3 workgroups per CU over the whole launch
+            int mpb2 = (M + sp - 1) / sp;
+            mpb2 = ((mpb2 + 63) / 64) * 64;
+            sp = (M + mpb2 - 1) / mpb2;
+            OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(tiles2 * sp), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2);
+            OD_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const int tiles = ((N + BN - 1) / BN) * ((K + BM - 1) / BM);
     int splits = (2048 + tiles - 1) / tiles;                 // aim for ~2048 workgroups (8 per CU)
     int mpb = (M + splits - 1) / splits;

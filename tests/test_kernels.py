@@ -39,7 +39,7 @@ def test_gemm_nt(dev, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (64, 16, 24), (1000, 130, 170)])
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (64, 16, 24), (1000, 130, 170), (600, 264, 300)])
 def test_gemm_tn_colsum(dev, dtype, M, N, K):
     g = torch.Generator().manual_seed(2)
     ldg, lda = (N + 7) // 8 * 8 + 8, (K + 7) // 8 * 8
