@@ -129,9 +129,12 @@ def test_train_step_directional_derivative_L8192(dev):
     loss, _ = tr(model, h, z, s, None, t=t, x0=x0)
     loss.backward()
     grad = model.arena.grad.clone()
-    d = torch.randn(model.arena.numel, device=dev, generator=g)
+    # direction: half along the gradient, the rest random (a purely random direction in 46.9 M dimensions has a
+    # directional derivative below the fp32 noise of the loss); eps sized for a ~0.1 % change of the loss
+    rnd = torch.randn(model.arena.numel, device=dev, generator=g)
+    d = 0.5 * grad / grad.norm() + math.sqrt(0.75) * rnd / rnd.norm()
     d = d / d.norm()
-    eps = 2e-3
+    eps = 0.03 / float((grad.double() * d.double()).sum().abs())
     base = model.arena.data.clone()
     vals = []
     for sgn in (+1, -1):
@@ -142,7 +145,7 @@ def test_train_step_directional_derivative_L8192(dev):
     model.arena.data.copy_(base)
     fd = (vals[0] - vals[1]) / (2 * eps)
     an = float((grad.double() * d.double()).sum())
-    assert abs(fd - an) <= 2e-2 * abs(an) + 1e-3, (fd, an)
+    assert abs(fd - an) <= 2e-2 * abs(an), (fd, an, eps)
 
 
 def test_sampler_graph_equals_eager_config3(dev):
