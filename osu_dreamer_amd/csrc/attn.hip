@@ -606,7 +606,13 @@ extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* 
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
 #define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st
-    if (dtype == OD_BF16 && hd == 64) return launch_bwd<bf16_t, 64, 2, 2>(ARGS);
+#ifndef OD_BWD_NK
+#define OD_BWD_NK 2
+#endif
+#ifndef OD_BWD_NQ
+#define OD_BWD_NQ 2
+#endif
+    if (dtype == OD_BF16 && hd == 64) return launch_bwd<bf16_t, 64, OD_BWD_NK, OD_BWD_NQ>(ARGS);
     if (dtype == OD_BF16 && hd == 32) return launch_bwd<bf16_t, 32, 2, 2>(ARGS);
     if (dtype == OD_F32 && hd == 64) return launch_bwd<float, 64, 1, 1>(ARGS);
     if (dtype == OD_F32 && hd == 32) return launch_bwd<float, 32, 1, 1>(ARGS);
