@@ -54,13 +54,15 @@ struct Stage {
     }
     // LDS-DMA of the same row-major swizzled image (no VGPRs, no ds_write): the block's 4 waves each
     // stream 1 KiB pieces = (1024 / ROWB) tile rows; the swizzle is applied to the source column.
+    template <int NW = 4>
     static __device__ __forceinline__ void dma_rowmajor(const T* base, int ld, int row0, int nrows, unsigned char* t) {
         constexpr int RPP = 1024 / ROWB;                   // rows per piece
-        constexpr int NP = BYTES / 1024 / 4;               // pieces per wave
+        constexpr int PIECES = BYTES / 1024;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const int piece = wave * NP + i;
+        for (int i = 0; i < (PIECES + NW - 1) / NW; i++) {
+            const int piece = wave + NW * i;
+            if (PIECES % NW != 0 && piece >= PIECES) break;
             const int row = piece * RPP + lane / CPR;
             const int slot = (lane % CPR) ^ (row & (CPR - 1));
             int gr = row0 + row; gr = gr < nrows ? gr : nrows - 1;
@@ -102,15 +104,16 @@ __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d
 
 // ======================================================================== forward
 // block: 4 waves x 32 query rows; loop over 64-key tiles, double-buffered in LDS.
-template <class T, int HD>
-__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+template <class T, int HD, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                            const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
                                                            float* __restrict__ lse, int B, int H, int L, float scale) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32;   // 32-deep slabs over the head dim
     constexpr int ND = HD / 16;   // 16-row tiles over the head dim
     OD_DYN_SMEM(smem);   // 2 stages x (K row-major, V row-major [bf16] or V^T [f32])
-    const int nqt = (L + 127) / 128;
+    constexpr int QB = NW * 32;
+    const int nqt = (L + QB - 1) / QB;
     int qt, bh;
     if (!attn_block_coords(nqt, B * H, qt, bh)) return;
     const int b = bh / H, h = bh % H;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
     const T* qb = q + (size_t)b * L * ldq + h * HD;
     const T* kb = k + (size_t)b * L * ldk + h * HD;
     const T* vb = v + (size_t)b * L * ldv + h * HD;
-    const int q0 = qt * 128 + wave * 32;
+    const int q0 = qt * QB + wave * 32;
     const float c = scale * LOG2E;
 
     od_frag<T> fq[2][NS];
@@ -145,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(const T* __restrict__
     };
     // bf16: K/V tiles go global -> LDS by LDS-DMA; f32 (V must be transposed) stages through registers
     auto dma = [&](int kt, unsigned char* base) {
-        St::dma_rowmajor(kb, ldk, kt * 64, L, base);
-        St::dma_rowmajor(vb, ldv, kt * 64, L, base + St::BYTES);
+        St::template dma_rowmajor<NW>(kb, ldk, kt * 64, L, base);
+        St::template dma_rowmajor<NW>(vb, ldv, kt * 64, L, base + St::BYTES);
     };
     if constexpr (St::TR) dma(0, smem);
     else { sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L); lstore(smem); }
@@ -439,13 +442,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
 
 // dQ: block owns 4 waves x NQ*16 queries; loop over 64-key tiles.
 //   S^T = K Q^T ; dP^T = V dO^T ; dS^T = P^T*(dP^T - delta)*scale ; dQ^T += K^T dS^T
-template <class T, int HD, int NQ>
-__global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+template <class T, int HD, int NQ, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                               const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               T* __restrict__ dq, int lddq, int B, int H, int L, float scale) {
     using St = Stage<T, HD>;
-    constexpr int NS = HD / 32, ND = HD / 16, QB = 4 * NQ * 16;
+    constexpr int NS = HD / 32, ND = HD / 16, QB = NW * NQ * 16;
     constexpr int NSTAGE = St::TR ? 2 : 1;
     constexpr int STAGE = (2 + St::NT) * St::BYTES;      // K, V (+ K^T for f32)
     OD_DYN_SMEM(smem);
@@ -487,8 +490,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
         if constexpr (!St::TR) sk.store_transposed(st + 2 * St::BYTES);
     };
     auto dma = [&](int kt, unsigned char* st) {
-        St::dma_rowmajor(kb, ldk, kt * 64, L, st);
-        St::dma_rowmajor(vb, ldv, kt * 64, L, st + St::BYTES);
+        St::template dma_rowmajor<NW>(kb, ldk, kt * 64, L, st);
+        St::template dma_rowmajor<NW>(vb, ldv, kt * 64, L, st + St::BYTES);
     };
     if constexpr (St::TR) dma(0, smem);
     else { sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L); lstore(smem); }
@@ -560,11 +563,15 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq_kernel(const T* __restric
     }
 }
 
+#ifndef OD_ATTN_NW
+#define OD_ATTN_NW 4      // waves per workgroup of the bf16 forward / dQ kernels.  6 (K/V streamed once per 192 queries) measured 0.71x: a 6-wave group lands 2,2,1,1 on the SIMDs and a second group no longer fits at 3 waves/SIMD
+#endif
 template <class T, int HD>
 int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* lse, int B,
                int H, int L, float scale, hipStream_t st) {
-    const int grid = attn_grid((L + 127) / 128, B * H);
-    OD_LAUNCH_DYN((flash_fwd_kernel<T, HD>), dim3(grid), dim3(256), (4 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+    constexpr int NW = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
+    const int grid = attn_grid((L + NW * 32 - 1) / (NW * 32), B * H);
+    OD_LAUNCH_DYN((flash_fwd_kernel<T, HD, NW>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (T*)o, ldo, lse, B, H, L, scale);
     OD_CHECK_LAUNCH();
     return 0;
@@ -580,8 +587,9 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     const int gk = attn_grid((L + 64 * NK - 1) / (64 * NK), B * H);
     OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK>), dim3(gk), dim3(256), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale);
-    const int gq = attn_grid((L + 64 * NQ - 1) / (64 * NQ), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ>), dim3(gq), dim3(256), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+    constexpr int NWQ = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
+    const int gq = attn_grid((L + 16 * NQ * NWQ - 1) / (16 * NQ * NWQ), B * H);
+    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ, NWQ>), dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale);
     OD_CHECK_LAUNCH();
     return 0;
