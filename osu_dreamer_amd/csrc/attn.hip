@@ -105,7 +105,7 @@ __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d
 // ======================================================================== forward
 // block: 4 waves x 32 query rows; loop over 64-key tiles, double-buffered in LDS.
 template <class T, int HD, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+__global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                            const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
                                                            float* __restrict__ lse, int B, int H, int L, float scale) {
     using St = Stage<T, HD>;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
 // dQ: block owns 4 waves x NQ*16 queries; loop over 64-key tiles.
 //   S^T = K Q^T ; dP^T = V dO^T ; dS^T = P^T*(dP^T - delta)*scale ; dQ^T += K^T dS^T
 template <class T, int HD, int NQ, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 6 ? 3 : 2)) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+__global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                               const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               T* __restrict__ dq, int lddq, int B, int H, int L, float scale) {

@@ -8,6 +8,9 @@
 
 namespace {
 
+#ifndef OD_QK_HEAD
+#define OD_QK_HEAD 1
+#endif
 constexpr int ROWS_PER_WAVE_BWD = 16;  // rows a wave walks in kernels that also reduce over frames
 
 // load a row chunk-wise into registers: lane owns chunks lane, lane+64, ... of 8 channels
@@ -522,6 +525,129 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const T* __restri
     }
 }
 
+// ---- q/k RMSNorm + RoPE, lane-per-head variant (hd = 32 / 64, 2H | 64) -------------------------
+// A lane owns one whole head of one frame (hd contiguous features): the RMS reduction and the rotary
+// pairing (d, d + hd/2) are lane-local — no cross-lane traffic — and a wave moves its 64 heads with
+// hd/8 16-byte loads + stores per lane.  The frame's cos/sin row and the norm weights come from LDS.
+// Fewer, fatter vector-memory instructions per byte than the chunk-per-lane kernel above.
+template <class T, int HD>
+__global__ __launch_bounds__(256) void qk_norm_rope_head_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
+                                                                const float* __restrict__ wk, const float* __restrict__ table,
+                                                                T* __restrict__ out, int ldo, long M, int L, int H, float eps) {
+    constexpr int HALF = HD / 2;
+    __shared__ float s_w[2][HD];
+    __shared__ __attribute__((aligned(16))) float s_tab[64][HD];       // (cos,sin) x HALF per frame of the block
+    const int nslot = 2 * H;                      // head slots per frame (q heads then k heads)
+    const int rpw = 64 / nslot;                   // frames per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long m0 = (long)blockIdx.x * 4 * rpw;   // first frame of the block
+    for (int i = threadIdx.x; i < 2 * HD; i += 256) s_w[i / HD][i % HD] = (i < HD ? wq[i] : wk[i - HD]);
+    for (int i = threadIdx.x; i < 4 * rpw * HD; i += 256) {
+        const long m = m0 + i / HD;
+        s_tab[i / HD][i % HD] = m < M ? table[(size_t)(m % L) * HD + (i % HD)] : 0.f;
+    }
+    __syncthreads();
+    const int fr = wave * rpw + lane / nslot, slot = lane % nslot;
+    const long m = m0 + fr;
+    if (m >= M) return;
+    const T* src = qkv + m * ldqkv + (size_t)slot * HD;
+    float v[HD];
+#pragma unroll
+    for (int c = 0; c < HD / 8; c++) {
+        float t8[8]; od_ld8(src + c * 8, t8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[c * 8 + e] = t8[e];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d++) ss += v[d] * v[d];
+    const float inv = rsqrtf(ss / (float)HD + eps);
+    const float* w = s_w[slot < H ? 0 : 1];
+    const float* tb = s_tab[fr];
+    float o[HD];
+#pragma unroll
+    for (int j = 0; j < HALF; j++) {
+        const float y1 = v[j] * inv * w[j], y2 = v[j + HALF] * inv * w[j + HALF];
+        const float cs = tb[2 * j], sn = tb[2 * j + 1];
+        o[j] = y1 * cs - y2 * sn;
+        o[j + HALF] = y1 * sn + y2 * cs;
+    }
+    T* dst = out + m * ldo + (size_t)slot * HD;
+#pragma unroll
+    for (int c = 0; c < HD / 8; c++) {
+        float t8[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) t8[e] = o[c * 8 + e];
+        od_st8(dst + c * 8, t8);
+    }
+}
+
+// backward of the above; a wave walks `iters` frame groups so the per-feature weight gradients
+// accumulate in registers and meet in LDS once per block.
+template <class T, int HD>
+__global__ __launch_bounds__(256) void qk_norm_rope_head_bwd_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
+                                                                    const float* __restrict__ wk, const float* __restrict__ table,
+                                                                    const T* __restrict__ dqk, int lddqk, T* __restrict__ dqkv, int lddqkv,
+                                                                    float* __restrict__ dwq, float* __restrict__ dwk,
+                                                                    long M, int L, int H, float eps, int iters) {
+    constexpr int HALF = HD / 2;
+    __shared__ float s_w[2][HD];
+    __shared__ float s_dw[2][HD];
+    const int nslot = 2 * H, rpw = 64 / nslot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * HD; i += 256) { s_w[i / HD][i % HD] = (i < HD ? wq[i] : wk[i - HD]); s_dw[i / HD][i % HD] = 0.f; }
+    __syncthreads();
+    const int slot = lane % nslot;
+    const float* w = s_w[slot < H ? 0 : 1];
+    float acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d++) acc[d] = 0.f;
+    for (int it = 0; it < iters; it++) {
+        const long m = (((long)blockIdx.x * iters + it) * 4 + wave) * rpw + lane / nslot;
+        if (m >= M) continue;
+        const T* src = qkv + m * ldqkv + (size_t)slot * HD;
+        const T* gsrc = dqk + m * lddqk + (size_t)slot * HD;
+        float v[HD], dy[HD];
+#pragma unroll
+        for (int c = 0; c < HD / 8; c++) {
+            float t8[8], g8[8]; od_ld8(src + c * 8, t8); od_ld8(gsrc + c * 8, g8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { v[c * 8 + e] = t8[e]; dy[c * 8 + e] = g8[e]; }
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d++) ss += v[d] * v[d];
+        const float inv = rsqrtf(ss / (float)HD + eps);
+        const float* tb = table + (size_t)(m % L) * HD;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < HALF; j++) {
+            const float cs = tb[2 * j], sn = tb[2 * j + 1];
+            const float d1 = dy[j] * cs + dy[j + HALF] * sn;          // un-rotate
+            const float d2 = -dy[j] * sn + dy[j + HALF] * cs;
+            const float x1 = v[j] * inv, x2 = v[j + HALF] * inv;
+            acc[j] += d1 * x1; acc[j + HALF] += d2 * x2;
+            const float e1 = d1 * w[j], e2 = d2 * w[j + HALF];
+            dot += e1 * x1 + e2 * x2;
+            dy[j] = e1; dy[j + HALF] = e2; v[j] = x1; v[j + HALF] = x2;
+        }
+        dot /= (float)HD;
+        T* dst = dqkv + m * lddqkv + (size_t)slot * HD;
+#pragma unroll
+        for (int c = 0; c < HD / 8; c++) {
+            float t8[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) t8[e] = inv * (dy[c * 8 + e] - v[c * 8 + e] * dot);
+            od_st8(dst + c * 8, t8);
+        }
+    }
+    float* sd = s_dw[slot < H ? 0 : 1];
+#pragma unroll
+    for (int d = 0; d < HD; d++) atomicAdd(&sd[d], acc[d]);
+    __syncthreads();
+    if (threadIdx.x < HD) { atomicAdd(dwq + threadIdx.x, s_dw[0][threadIdx.x]); atomicAdd(dwk + threadIdx.x, s_dw[1][threadIdx.x]); }
+}
+
 __global__ void rope_table_kernel(float* __restrict__ table, int L, int hd) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int half = hd / 2;
@@ -665,6 +791,16 @@ extern "C" int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const floa
     if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
     if (ldqkv % 8 || ldo % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
+    if (OD_QK_HEAD && (hd == 64 || hd == 32) && 64 % (2 * H) == 0) {       // lane-per-head kernel
+        const int rpw = 64 / (2 * H);
+        dim3 g2((unsigned)((M + 4 * rpw - 1) / (4 * rpw)));
+#define QKH(TT, HDV) OD_LAUNCH((qk_norm_rope_head_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (TT*)qk_out, ldo, M, L, H, eps)
+        if (dtype == OD_BF16) { if (hd == 64) QKH(bf16_t, 64); else QKH(bf16_t, 32); }
+        else { if (hd == 64) QKH(float, 64); else QKH(float, 32); }
+#undef QKH
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((unsigned)((M + 3) / 4));
     if (dtype == OD_BF16)
         OD_LAUNCH((qk_norm_rope_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,
@@ -682,6 +818,16 @@ extern "C" int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const 
     if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
     if (ldqkv % 8 || lddqk % 8 || lddqkv % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
+    if (OD_QK_HEAD && (hd == 64 || hd == 32) && 64 % (2 * H) == 0) {       // lane-per-head kernel
+        const int rpw = 64 / (2 * H), iters = 16;
+        dim3 g2((unsigned)((M + 4L * rpw * iters - 1) / (4L * rpw * iters)));
+#define QKHB(TT, HDV) OD_LAUNCH((qk_norm_rope_head_bwd_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (const TT*)dqk, lddqk, (TT*)dqkv, lddqkv, dwq, dwk, M, L, H, eps, iters)
+        if (dtype == OD_BF16) { if (hd == 64) QKHB(bf16_t, 64); else QKHB(bf16_t, 32); }
+        else { if (hd == 64) QKHB(float, 64); else QKHB(float, 32); }
+#undef QKHB
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((unsigned)((M + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD)));
     if (dtype == OD_BF16)
         OD_LAUNCH((qk_norm_rope_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,

@@ -47,6 +47,17 @@ def main():
         t = timeit(lambda: ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], o, do, lse, delta, dqk[:, :dh],
                                               dqk[:, dh:], dqkv[:, 2 * dh:], B, H, L, hd, sc), a.iters)
         print(f"flash_bwd  {t:8.3f} ms  {7 * unit / t / 1e9:7.1f} TF/s (7 passes)")
+    if a.what in ("rope", "all"):
+        qkv, qk = r(M, 3 * dh), torch.zeros(M, 2 * dh, dtype=bf, device=dev)
+        wq, wk = torch.ones(hd, device=dev), torch.ones(hd, device=dev)
+        tab = torch.zeros(L, hd // 2, 2, device=dev); ops.rope_table(tab, L, hd)
+        eps = 1.2e-7
+        t = timeit(lambda: ops.qk_norm_rope(qkv, wq, wk, tab, qk, B, L, H, hd, eps), a.iters)
+        print(f"qk_norm_rope fwd {t:8.3f} ms  {M * 2 * dh * 2 * 2 / t / 1e6:7.1f} GB/s")
+        dqk, dqkv2 = r(M, 2 * dh), torch.zeros(M, 3 * dh, dtype=bf, device=dev)
+        dwq, dwk = torch.zeros(hd, device=dev), torch.zeros(hd, device=dev)
+        t = timeit(lambda: ops.qk_norm_rope_bwd(qkv, wq, wk, tab, dqk, dqkv2, dwq, dwk, B, L, H, hd, eps), a.iters)
+        print(f"qk_norm_rope bwd {t:8.3f} ms  {M * 2 * dh * 2 * 3 / t / 1e6:7.1f} GB/s")
     if a.what in ("gemm", "all"):
         for name, N, K in (("qkv", 3072, 512), ("out", 512, 1024), ("vg", 2816, 512), ("proj_o", 512, 1408), ("cl", 512, 128),
                            ("d_qkv", 512, 3072), ("d_vg", 512, 2816)):
