@@ -629,7 +629,10 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
         const int tiles2 = ((N + 255) / 256) * ((K + 255) / 256);
         // few output tiles => many M-splits => the fp32 atomics of the epilogue dominate: stay on 128x128 there
         if (M >= OD_GEMM_BIG_MIN_M && N >= 256 && K >= 256 && (tiles2 >= 10 || OD_GEMM_BIG_MIN_M < 32768)) {
-            int sp = (768 + tiles2 - 1) / tiles2;             // ~3 workgroups per CU over the whole launch
+#ifndef OD_TN_BLOCKS
+#define OD_TN_BLOCKS 256     // one workgroup per CU: M-splits = 256 / output tiles (fewest fp32 atomics, no second block wave)
+#endif
+            int sp = OD_TN_BLOCKS >= 512 ? (OD_TN_BLOCKS + tiles2 - 1) / tiles2 : (OD_TN_BLOCKS / tiles2 > 0 ? OD_TN_BLOCKS / tiles2 : 1);
             int mpb2 = (M + sp - 1) / sp;
             mpb2 = ((mpb2 + 63) / 64) * 64;
             sp = (M + mpb2 - 1) / mpb2;
