@@ -173,6 +173,17 @@ int od_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long 
  * average is updated outside the fused pass. */
 int od_ema_update(float* ema, const float* p, long n, float ema_decay, int ema_mode, void* stream);
 
+/* ---- style-model sampler (models/style/model.py:73-119; the rest of it reuses od_linear_small,
+ *      od_rmsnorm_film / od_rmsnorm_gate_residual with L = 1, od_uhead_tail, od_sampler_eta, od_sampler_step) */
+/* c[B,H] = sum over the NL labels of (label < 0 ? null[n] : cond_b[n] + rff(label/10) . cond_w[n]),
+ * rff(x)[f] = sqrt(2/F) cos(x*rff_w[f] + rff_b[f]).  replaces: style/model.py:73-80 + common/fourier_features.py:15. */
+int od_style_conditioning(const float* labels, const float* rff_w, const float* rff_b, const float* cond_w,
+                          const float* cond_b, const float* null_labels, float* c, int B, int NL, int F, int H,
+                          void* stream);
+/* y[M,C] = x * rsqrt(mean_c x^2 + eps) (* gamma[C] if non-NULL), fp32.  replaces: nn.RMSNorm at style/model.py:50
+ * and rms_norm at :99. */
+int od_rmsnorm_rows(const float* x, const float* gamma, float* y, int M, int C, float eps, void* stream);
+
 /* ---- hipGraph helpers for the captured sampler loop ---------------------------------- */
 int od_graph_begin(void* stream);
 int od_graph_end(void* stream, void** graph_exec_out);

@@ -265,6 +265,44 @@ def gen_lr(out_dir):
              mult=np.array([f(int(s)) for s in steps]))
 
 
+def gen_style(out_dir, name, d, B, seed):
+    """Style-model fixtures from the reference's StyleModel (models/style/model.py)."""
+    from oracle import style_oracle as SO
+    from osu_dreamer.models.style.model import StyleModel, StyleModelArgs
+    import osu_dreamer.models.style.model as style_mod
+    P = SO.init_style_params(d, seed)
+    m = StyleModel(d.style_dim, StyleModelArgs(label_features=d.label_features, h_dim=d.h_dim, depth=d.depth, expand=d.expand))
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(P.keys()), (sorted(sd.keys()), sorted(P.keys()))
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(P[k].shape), k
+    m.load_state_dict(P)
+    m.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    labels = torch.rand(B, 5, generator=g) * 10
+    labels[0, 1] = -1.0                      # a dropped label (null embedding path)
+    if B > 2:
+        labels[2, :] = -1.0
+    st = torch.randn(B, d.style_dim, generator=g)
+    s_init = torch.randn(B, d.style_dim, generator=g)
+    with torch.no_grad():
+        c = m.compute_conditioning(labels)
+        u, v = m(st, labels)
+    saved = style_mod.th.randn
+    style_mod.th.randn = lambda *a, **k: s_init.clone()
+    try:
+        ss = m.sample(labels, 16)
+    finally:
+        style_mod.th.randn = saved
+    fx = {"dims": np.array([d.style_dim, d.label_features, d.h_dim, d.depth, d.expand]), "seed": seed, "B": B,
+          "labels": labels, "st": st, "s_init": s_init, "cond": c, "fwd_u": u, "fwd_v": v, "sample_s": ss}
+    if d.h_dim <= 64:
+        for k, w in P.items():
+            fx["w." + k] = w
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
+    print(name, "u", u.tolist()[:3])
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -273,6 +311,11 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     gen_lr(out_dir)
     gen_ops(out_dir)
+    from oracle import style_oracle as SO
+    gen_style(out_dir, "style_tiny", SO.STYLE_TINY, B=3, seed=500)
+    gen_style(out_dir, "style_full", SO.STYLE_FULL, B=4, seed=600)
+    if os.environ.get("GOLDEN_ONLY") == "style":
+        return
     # tiny config: weights + every gradient stored (a few hundred KB)
     gen_model(out_dir, "tiny_b3_l40", O.TINY, B=3, L=40, seed=100, store_weights=True, with_bf16=True)
     # tiny config, broadcast audio (sampler semantics '#B A l', model.py:120) and ragged L

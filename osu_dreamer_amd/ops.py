@@ -303,3 +303,18 @@ def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, weight_decay, step, ema_de
 def ema_update(ema, p, decay, mode):
     _f32(ema, p)
     _lib.lib().od_ema_update(_p(ema), _p(p), p.numel(), decay, mode, _stream(p))
+
+
+# ---------------------------------------------------------------- style model
+def style_conditioning(labels, rff_w, rff_b, cond_w, cond_b, null_labels, c):
+    B, NL = labels.shape
+    F, H = cond_w.shape[1], cond_w.shape[2]
+    _f32(labels, rff_w, rff_b, cond_w, cond_b, null_labels, c)
+    _lib.lib().od_style_conditioning(_p(labels), _p(rff_w), _p(rff_b), _p(cond_w), _p(cond_b), _p(null_labels), _p(c),
+                                     B, NL, F, H, _stream(labels))
+
+
+def rmsnorm_rows(x, gamma, y, eps):
+    M, C = x.shape
+    _f32(x, gamma, y)
+    _lib.lib().od_rmsnorm_rows(_p(x), _p(gamma), _p(y), M, C, eps, _stream(x))

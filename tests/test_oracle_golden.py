@@ -113,3 +113,25 @@ def test_reference_bf16_error_is_recorded():
     fx = load("tiny_b3_l40")
     e = rel_l2(fx["fwd_v_bf16"], fx["fwd_v"])
     assert 1e-4 < e < 5e-2
+
+
+# ---------------------------------------------------------------- style model sampler
+def _style_case(name):
+    from oracle import style_oracle as SO
+    fx = load(name)
+    v = [int(x) for x in fx["dims"].tolist()]
+    d = SO.StyleDims(style_dim=v[0], label_features=v[1], h_dim=v[2], depth=v[3], expand=v[4])
+    P = ({k[2:]: t for k, t in fx.items() if k.startswith("w.")} if any(k.startswith("w.") for k in fx)
+         else SO.init_style_params(d, int(fx["seed"])))
+    return SO, fx, d, P
+
+
+@pytest.mark.parametrize("name", ["style_tiny", "style_full"])
+def test_style_oracle_vs_reference(name):
+    SO, fx, d, P = _style_case(name)
+    with torch.no_grad():
+        assert rel_l2(SO.conditioning(fx["labels"], P, d), fx["cond"]) < 2e-6
+        u, v = SO.style_forward(fx["st"], fx["labels"], P, d)
+        assert rel_l2(u, fx["fwd_u"]) < 2e-6 and rel_l2(v, fx["fwd_v"]) < 5e-6
+        s = SO.style_sample(fx["labels"], 16, fx["s_init"], P, d)
+        assert rel_l2(s, fx["sample_s"]) < 1e-4
