@@ -24,11 +24,19 @@ class CapturedLoop:
             finally:
                 L.od_graph_end(self.stream.cuda_stream, ctypes.byref(self._exec))
 
+    def begin(self):
+        """Order the side stream after everything already queued on the caller's stream."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
     def replay(self):
         _lib.lib().od_graph_launch(self._exec, self.stream.cuda_stream)
 
-    def close(self):
+    def end(self):
+        """Make the caller's stream wait for the replays."""
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def close(self):
+        self.end()
         if self._exec:
             self.stream.synchronize()
             _lib.lib().od_graph_destroy(self._exec)

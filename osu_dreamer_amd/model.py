@@ -291,11 +291,19 @@ class DiffusionModel(nn.Module):
             except ImportError:
                 pass
         if self.use_graph and dev.type == "cuda" and num_steps > 1:
+            # the captured step only references plan-owned buffers (x, u, v, eta, workspace, packed weights),
+            # so one instantiated graph serves every later call with the same plan
             from .graph import CapturedLoop
-            loop = CapturedLoop(step, dev)
+            key = (eng._plan_key, eng._packed_key)
+            if self._graph is None or self._graph[0] != key:
+                if self._graph is not None:
+                    self._graph[1].close()
+                self._graph = (key, CapturedLoop(step, dev))
+            loop = self._graph[1]
+            loop.begin()
             for _ in steps:
                 loop.replay()
-            loop.close()
+            loop.end()
         else:
             for _ in steps:
                 step()

@@ -157,10 +157,16 @@ class StyleModel(nn.Module):
 
         if self.use_graph and dev.type == "cuda" and num_steps > 1:
             from .graph import CapturedLoop
-            loop = CapturedLoop(step, dev)
+            key = (B, dev, tuple(t.data_ptr() for t in W.values()))
+            if getattr(self, "_graph", None) is None or self._graph[0] != key:
+                if getattr(self, "_graph", None) is not None:
+                    self._graph[1].close()
+                self._graph = (key, CapturedLoop(step, dev))
+            loop = self._graph[1]
+            loop.begin()
             for _ in range(num_steps):
                 loop.replay()
-            loop.close()
+            loop.end()
         else:
             for _ in range(num_steps):
                 step()
