@@ -155,7 +155,8 @@ def cpu_baseline(L_cpu=2048):
 
 def sampler_bench(device):
     """BASELINE configs[3]: 50-step sampler, 4 diffs in parallel on a 3-min song (L=1115 latent frames),
-    fp32 compute (the 1e-4 parity mode), hipGraph-captured step."""
+    hipGraph-captured step.  fp32 = exact fp32 MFMA chain, fp32_bf16x3 = fp32 tensors with 3 bf16 MFMAs per
+    product (both inside the 1e-4 sampler parity bound), bf16 = autocast-equivalent compute."""
     from osu_dreamer_amd.model import DiffusionModel
     a = default_model_args()
     torch.manual_seed(5)
@@ -170,8 +171,9 @@ def sampler_bench(device):
     h = torch.randn(1, 128, L, generator=g).to(device)
     s = torch.randn(B, 32, generator=g).to(device)
     out = {}
-    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        m.compute_dtype = dt
+    for name, dt, mm in (("fp32", torch.float32, "f32"), ("fp32_bf16x3", torch.float32, "bf16x3"),
+                         ("bf16", torch.bfloat16, "f32")):
+        m.compute_dtype, m.f32_matmul = dt, mm
         m.sample(h, s, 50)
         torch.cuda.synchronize()
         t0 = time.time()

@@ -24,7 +24,11 @@
 extern "C" {
 #endif
 
-enum { OD_F32 = 0, OD_BF16 = 1 };
+enum { OD_F32 = 0, OD_BF16 = 1,
+       /* fp32 tensors, products as 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~4e-6 relative
+        * error per GEMM instead of 4e-7, 1.7x the fp32 rate.  Accepted by od_gemm_nt and od_flash_attn_fwd
+        * only (the no-grad forward / sampler); every other entry point takes OD_F32 for such tensors. */
+       OD_F32X3 = 2 };
 enum { OD_EPI_NONE = 0, OD_EPI_SILU = 1 };
 enum { OD_ACT_NONE = 0, OD_ACT_SILU = 1 };
 enum { OD_ERR_ARG = -1, OD_ERR_ALIGN = -2, OD_ERR_UNSUPPORTED = -3 };

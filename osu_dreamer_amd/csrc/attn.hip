@@ -101,6 +101,7 @@ __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d
     f32x4 v; v[0] = a; v[1] = b; v[2] = c; v[3] = d;
     *(f32x4*)p = v;
 }
+__device__ __forceinline__ void st4(f32x3_t* p, float a, float b, float c, float d) { st4((float*)p, a, b, c, d); }
 
 // ======================================================================== forward
 // block: 4 waves x 32 query rows; loop over 64-key tiles, double-buffered in LDS.
@@ -605,6 +606,8 @@ extern "C" int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* 
     if (dtype == OD_BF16 && hd == 32) return launch_fwd<bf16_t, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
     if (dtype == OD_F32 && hd == 64) return launch_fwd<float, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
     if (dtype == OD_F32 && hd == 32) return launch_fwd<float, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
+    if (dtype == OD_F32X3 && hd == 64) return launch_fwd<f32x3_t, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
+    if (dtype == OD_F32X3 && hd == 32) return launch_fwd<f32x3_t, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
     return OD_ERR_UNSUPPORTED;
 }
 

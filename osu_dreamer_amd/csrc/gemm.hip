@@ -30,12 +30,20 @@ template <>
 __device__ __forceinline__ void frag_from_lds<bf16_t>(od_frag<bf16_t>& f, const unsigned char* tile, int row, int slab, int g) {
     f.v = *(const s16x8*)(tile + swz(row, slab * 4 + g));
 }
-template <>
-__device__ __forceinline__ void frag_from_lds<float>(od_frag<float>& f, const unsigned char* tile, int row, int slab, int g) {
+template <class F>
+__device__ __forceinline__ void frag_from_lds_f32(od_frag<F>& f, const unsigned char* tile, int row, int slab, int g) {
     f32x4 a = *(const f32x4*)(tile + swz(row, slab * 8 + 2 * g));
     f32x4 b = *(const f32x4*)(tile + swz(row, slab * 8 + 2 * g + 1));
-    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+    const float x8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    od_frag_pack(f, x8);
+}
+template <>
+__device__ __forceinline__ void frag_from_lds<float>(od_frag<float>& f, const unsigned char* tile, int row, int slab, int g) {
+    frag_from_lds_f32(f, tile, row, slab, g);
+}
+template <>
+__device__ __forceinline__ void frag_from_lds<f32x3_t>(od_frag<f32x3_t>& f, const unsigned char* tile, int row, int slab, int g) {
+    frag_from_lds_f32(f, tile, row, slab, g);
 }
 
 // One 128-byte-deep slab of MFMAs from a staged (A,B) pair.
@@ -663,6 +671,8 @@ extern "C" int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int 
         return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
     if (dtype == OD_F32)
         return launch_nt<float>((const float*)A, lda, (const float*)W, ldw, bias, (float*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
+    if (dtype == OD_F32X3)
+        return launch_nt<f32x3_t>((const f32x3_t*)A, lda, (const f32x3_t*)W, ldw, bias, (f32x3_t*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
     return OD_ERR_ARG;
 }
 

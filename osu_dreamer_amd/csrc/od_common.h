@@ -62,7 +62,14 @@ __device__ __forceinline__ uint32_t od_pack_bf2(float lo, float hi) {
 __device__ __forceinline__ float od_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif
 
+// compute-type tag: fp32 storage whose MFMA products run as 3 bf16 MFMAs (OD_F32X3, inference only)
+struct f32x3_t { float x; };
+
 template <class T> struct od_t;
+template <> struct od_t<f32x3_t> {
+    static __device__ __forceinline__ float ld(const f32x3_t* p) { return p->x; }
+    static __device__ __forceinline__ void st(f32x3_t* p, float v) { p->x = v; }
+};
 template <> struct od_t<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
@@ -93,6 +100,8 @@ __device__ __forceinline__ void od_st8(float* p, const float (&v)[8]) {
     b[0] = v[4]; b[1] = v[5]; b[2] = v[6]; b[3] = v[7];
     *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
 }
+__device__ __forceinline__ void od_ld8(const f32x3_t* p, float (&v)[8]) { od_ld8((const float*)p, v); }
+__device__ __forceinline__ void od_st8(f32x3_t* p, const float (&v)[8]) { od_st8((float*)p, v); }
 __device__ __forceinline__ void od_st8(bf16_t* p, const float (&v)[8]) {
     u32x4 r;
 #pragma unroll
@@ -125,16 +134,39 @@ __device__ __forceinline__ float od_silu_grad(float x) {
 template <class T> struct od_frag;
 template <> struct od_frag<bf16_t> { s16x8 v; };
 template <> struct od_frag<float> { float v[8]; };
+// f32x3: fp32 in memory, three bf16 MFMAs per product.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+// (|x - hi - lo| <= 2^-17 |x|);  a.b ~ ahi.bhi + ahi.blo + alo.bhi, accumulated in fp32.
+template <> struct od_frag<f32x3_t> { s16x8 hi, lo; };
+__device__ __forceinline__ void od_frag_pack(od_frag<float>& f, const float (&x)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) f.v[j] = x[j];
+}
+__device__ __forceinline__ void od_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = od_pack_bf2(a, b);
+    union { uint32_t u; float f; } x, y;
+    x.u = hi << 16; y.u = hi & 0xffff0000u;
+    lo = od_pack_bf2(a - x.f, b - y.f);
+}
+__device__ __forceinline__ void od_frag_pack(od_frag<f32x3_t>& f, const float (&x)[8]) {
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t a, b;
+        od_split2(x[2 * i], x[2 * i + 1], a, b);
+        h[i] = a; l[i] = b;
+    }
+    f.hi = __builtin_bit_cast(s16x8, h); f.lo = __builtin_bit_cast(s16x8, l);
+}
 
 __device__ __forceinline__ void od_frag_load(od_frag<bf16_t>& f, const bf16_t* p) { f.v = *(const s16x8*)p; }
 __device__ __forceinline__ void od_frag_load(od_frag<float>& f, const float* p) { od_ld8(p, f.v); }
+__device__ __forceinline__ void od_frag_load(od_frag<f32x3_t>& f, const f32x3_t* p) { float x[8]; od_ld8(p, x); od_frag_pack(f, x); }
 __device__ __forceinline__ void od_frag_zero(od_frag<bf16_t>& f) { f.v = (s16x8)(0); }
 __device__ __forceinline__ void od_frag_zero(od_frag<float>& f) {
 #pragma unroll
     for (int j = 0; j < 8; j++) f.v[j] = 0.f;
 }
-__device__ __forceinline__ void od_frag_set(od_frag<bf16_t>& f, int j, float x) { f.v[j] = (short)od_f2bf(x); }
-__device__ __forceinline__ void od_frag_set(od_frag<float>& f, int j, float x) { f.v[j] = x; }
+__device__ __forceinline__ void od_frag_zero(od_frag<f32x3_t>& f) { f.hi = (s16x8)(0); f.lo = (s16x8)(0); }
 // elements 4*half .. 4*half+3 of a fragment (half = 0 or 1)
 __device__ __forceinline__ void od_frag_set4(od_frag<bf16_t>& f, int half, float a, float b, float c, float d) {
     u32x4 w = __builtin_bit_cast(u32x4, f.v);
@@ -144,6 +176,14 @@ __device__ __forceinline__ void od_frag_set4(od_frag<bf16_t>& f, int half, float
 }
 __device__ __forceinline__ void od_frag_set4(od_frag<float>& f, int half, float a, float b, float c, float d) {
     f.v[4 * half] = a; f.v[4 * half + 1] = b; f.v[4 * half + 2] = c; f.v[4 * half + 3] = d;
+}
+__device__ __forceinline__ void od_frag_set4(od_frag<f32x3_t>& f, int half, float a, float b, float c, float d) {
+    u32x4 h = __builtin_bit_cast(u32x4, f.hi), l = __builtin_bit_cast(u32x4, f.lo);
+    uint32_t h0, l0, h1, l1;
+    od_split2(a, b, h0, l0);
+    od_split2(c, d, h1, l1);
+    h[2 * half] = h0; l[2 * half] = l0; h[2 * half + 1] = h1; l[2 * half + 1] = l1;
+    f.hi = __builtin_bit_cast(s16x8, h); f.lo = __builtin_bit_cast(s16x8, l);
 }
 
 // LDS transpose read (gfx950 ds_read_b64_tr_b16): within each 16-lane group, lane c supplies the
@@ -165,6 +205,11 @@ __device__ __forceinline__ f32x4 od_mma(const od_frag<float>& a, const od_frag<f
 #pragma unroll
     for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
     return c;
+}
+__device__ __forceinline__ f32x4 od_mma(const od_frag<f32x3_t>& a, const od_frag<f32x3_t>& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);  // small terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
 }
 
 // 16 zero bytes in global memory: the source of LDS-DMA lanes that fall outside a matrix

@@ -14,13 +14,17 @@ template <int ROWB>
 __device__ __forceinline__ void frag_contig(od_frag<bf16_t>& f, const unsigned char* t, int row, int k0) {
     f.v = *(const s16x8*)(t + tile_off<ROWB>(row, k0 * 2));
 }
-template <int ROWB>
-__device__ __forceinline__ void frag_contig(od_frag<float>& f, const unsigned char* t, int row, int k0) {
+template <int ROWB, class F>
+__device__ __forceinline__ void frag_contig_f32(od_frag<F>& f, const unsigned char* t, int row, int k0) {
     const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4));
     const f32x4 b = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4 + 16));
-    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+    const float x8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    od_frag_pack(f, x8);
 }
+template <int ROWB>
+__device__ __forceinline__ void frag_contig(od_frag<float>& f, const unsigned char* t, int row, int k0) { frag_contig_f32<ROWB>(f, t, row, k0); }
+template <int ROWB>
+__device__ __forceinline__ void frag_contig(od_frag<f32x3_t>& f, const unsigned char* t, int row, int k0) { frag_contig_f32<ROWB>(f, t, row, k0); }
 // permuted slab u: elements {32u+4g .. +3} and {32u+16+4g .. +3} of `row`
 template <int ROWB>
 __device__ __forceinline__ void frag_perm(od_frag<bf16_t>& f, const unsigned char* t, int row, int u, int g) {
@@ -29,13 +33,17 @@ __device__ __forceinline__ void frag_perm(od_frag<bf16_t>& f, const unsigned cha
     f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
     f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
 }
-template <int ROWB>
-__device__ __forceinline__ void frag_perm(od_frag<float>& f, const unsigned char* t, int row, int u, int g) {
+template <int ROWB, class F>
+__device__ __forceinline__ void frag_perm_f32(od_frag<F>& f, const unsigned char* t, int row, int u, int g) {
     const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, (32 * u + 4 * g) * 4));
     const f32x4 b = *(const f32x4*)(t + tile_off<ROWB>(row, (32 * u + 16 + 4 * g) * 4));
-    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+    const float x8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    od_frag_pack(f, x8);
 }
+template <int ROWB>
+__device__ __forceinline__ void frag_perm(od_frag<float>& f, const unsigned char* t, int row, int u, int g) { frag_perm_f32<ROWB>(f, t, row, u, g); }
+template <int ROWB>
+__device__ __forceinline__ void frag_perm(od_frag<f32x3_t>& f, const unsigned char* t, int row, int u, int g) { frag_perm_f32<ROWB>(f, t, row, u, g); }
 
 // "column" fragment: element j of lane (x, g) = tile[row 32u + 16*(j>>2) + 4g + (j&3)][col c0 + x].
 // bf16: two LDS transpose reads (ds_read_b64_tr_b16) from the ROW-MAJOR tile — no transposed copy
@@ -50,6 +58,10 @@ __device__ __forceinline__ void frag_cols(od_frag<bf16_t>& f, const unsigned cha
 }
 template <int ROWB, int TROWB>
 __device__ __forceinline__ void frag_cols(od_frag<float>& f, const unsigned char*, const unsigned char* t_tr, int c0, int x, int u, int g) {
+    frag_perm<TROWB>(f, t_tr, c0 + x, u, g);
+}
+template <int ROWB, int TROWB>
+__device__ __forceinline__ void frag_cols(od_frag<f32x3_t>& f, const unsigned char*, const unsigned char* t_tr, int c0, int x, int u, int g) {
     frag_perm<TROWB>(f, t_tr, c0 + x, u, g);
 }
 

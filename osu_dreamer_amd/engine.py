@@ -122,15 +122,18 @@ class DenoiserEngine:
         return self._packed[name + (".T" if T else "")]
 
     # ------------------------------------------------------------------ plan / workspace
-    def plan(self, B: int, L: int, Ba: int, dtype: torch.dtype, train: bool):
+    def plan(self, B: int, L: int, Ba: int, dtype: torch.dtype, train: bool, x3: bool = False):
+        """`x3`: run the fp32 forward's MFMA products as 3 bf16 MFMAs (OD_F32X3; no-grad paths only)."""
         dev = self.model.arena.data.device
-        key = (B, L, Ba, dtype, train, dev)
+        assert not (x3 and train), "the f32x3 product exists for the forward kernels only"
+        x3 = bool(x3 and dtype == torch.float32)
+        key = (B, L, Ba, dtype, train, dev, x3)
         if key != self._plan_key:
             self.ws = Workspace(dev)
             self._plan_key = key
             tab = self.ws.get("rope", (L, self.hd // 2, 2), torch.float32)
             ops.rope_table(tab, L, self.hd)
-        self.B, self.L, self.Ba, self.dtype, self.train = B, L, Ba, dtype, train
+        self.B, self.L, self.Ba, self.dtype, self.train, self.x3 = B, L, Ba, dtype, train, x3
         self.M, self.Ma = B * L, Ba * L
         return self.ws
 
@@ -153,7 +156,7 @@ class DenoiserEngine:
         a_pre = self.buf("a_pre", (self.Ma, A))
         a = self.buf("a", (self.Ma, A))
         ops.cl_to_frames(audio, a_t)
-        ops.gemm_nt(a_t, self.W("proj_audio.0"), self.P("proj_audio.0.bias"), a_pre)
+        ops.gemm_nt(a_t, self.W("proj_audio.0"), self.P("proj_audio.0.bias"), a_pre, x3=self.x3)
         ops.silu(a_pre, a)
         cg, cg_pre = self.buf("cg", (B, Cg), f32), self.buf("cg_pre", (B, Cg), f32)
         ops.linear_small(style, self.P("proj_style.0.weight"), self.P("proj_style.0.bias"), cg, cg_pre, OD_ACT_SILU)
@@ -163,7 +166,7 @@ class DenoiserEngine:
                 ops.linear_small(cg, self.P(p + s + ".weight"), self.P(p + s + ".bias"),
                                  self.buf(f"{s}.{i}", (B, 3 * D), f32))
             if not self.train:
-                ops.gemm_nt(a, self.W(p + "proj_cl"), self.P(p + "proj_cl.bias"), self.buf(f"cl.{i}", (self.Ma, D)))
+                ops.gemm_nt(a, self.W(p + "proj_cl"), self.P(p + "proj_cl.bias"), self.buf(f"cl.{i}", (self.Ma, D)), x3=self.x3)
         ops.linear_small(cg, self.P("u_mod.weight"), self.P("u_mod.bias"), self.buf("umod", (B, 2 * U), f32))
 
     # ------------------------------------------------------------------ forward (model.py:86-103)
@@ -179,23 +182,23 @@ class DenoiserEngine:
             ssg1, ssg2 = self.ws.t[f"ssg1.{i}"], self.ws.t[f"ssg2.{i}"]
             if self.train:
                 cl = self.buf("cl", (self.Ma, D))
-                ops.gemm_nt(self.ws.t["a"], self.W(p + "proj_cl"), self.P(p + "proj_cl.bias"), cl)
+                ops.gemm_nt(self.ws.t["a"], self.W(p + "proj_cl"), self.P(p + "proj_cl.bias"), cl, x3=self.x3)
             else:
                 cl = self.ws.t[f"cl.{i}"]
             # --- attention branch (backbone.py:76-80, attn.py:74-84)
             h1 = self.lbuf("h1", i, (M, D))
             ops.rmsnorm_film(x, ssg1, cl, bcast, h1, self.lbuf("inv1", i, (M,), f32), B, L)
             qkv = self.lbuf("qkv", i, (M, 3 * dh))
-            ops.gemm_nt(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv)
+            ops.gemm_nt(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv, x3=self.x3)
             qk = self.lbuf("qk", i, (M, 2 * dh))
             ops.qk_norm_rope(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, qk,
                              B, L, self.H, self.hd, FP32_EPS)
             y = self.lbuf("y", i, (M, dh))
             lse = self.lbuf("lse", i, (B, self.H, L), f32)
             ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, self.H, L, self.hd,
-                               1.0 / math.sqrt(self.hd))
+                               1.0 / math.sqrt(self.hd), x3=self.x3)
             ao = self.lbuf("ao", i, (M, D))
-            ops.gemm_nt(y, self.W(p + "attn.out_proj"), self.P(p + "attn.out_proj.bias"), ao)
+            ops.gemm_nt(y, self.W(p + "attn.out_proj"), self.P(p + "attn.out_proj.bias"), ao, x3=self.x3)
             x_mid = self.lbuf("x_mid", i, (M, D))
             ops.rmsnorm_gate_residual(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), B, L)
             # --- feed-forward branch (backbone.py:82-86, swiglu.py:27-32)
@@ -204,11 +207,11 @@ class DenoiserEngine:
             hdw = self.lbuf("hdw", i, (M, D))
             ops.dwconv(h2, self.P(p + "ffn.proj_vg.0.weight"), self.P(p + "ffn.proj_vg.0.bias"), hdw, B, L, self.ksize)
             vg = self.lbuf("vg", i, (M, 2 * Hp))
-            ops.gemm_nt(hdw, self.W(p + "ffn.proj_vg.1"), self._packed[p + "ffn.proj_vg.1.b"], vg)
+            ops.gemm_nt(hdw, self.W(p + "ffn.proj_vg.1"), self._packed[p + "ffn.proj_vg.1.b"], vg, x3=self.x3)
             hh = self.lbuf("hh", i, (M, Hp))
             ops.swiglu_rmsnorm(vg, hh, self.lbuf("inv4", i, (M,), f32), self.Hf, Hp)
             fo = self.lbuf("fo", i, (M, D))
-            ops.gemm_nt(hh, self.W(p + "ffn.proj_o"), self.P(p + "ffn.proj_o.bias"), fo)
+            ops.gemm_nt(hh, self.W(p + "ffn.proj_o"), self.P(p + "ffn.proj_o.bias"), fo, x3=self.x3)
             # next layer input; at inference x_in.0 / x_in.1 ping-pong
             x = self.buf(f"x_in.{i + 1}", (M, D)) if self.train else self.buf(f"x_in.{(i + 1) & 1}", (M, D))
             ops.rmsnorm_gate_residual(x_mid, fo, ssg2, x, self.lbuf("inv5", i, (M,), f32), B, L)

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import OD_ACT_NONE, OD_ACT_SILU, OD_BF16, OD_EPI_NONE, OD_EPI_SILU, OD_F32
+from ._lib import OD_ACT_NONE, OD_ACT_SILU, OD_BF16, OD_EPI_NONE, OD_EPI_SILU, OD_F32, OD_F32X3
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -20,6 +20,11 @@ def dt_code(dtype: torch.dtype) -> int:
     if dtype == torch.bfloat16:
         return OD_BF16
     raise TypeError(f"unsupported compute dtype {dtype}")
+
+
+def mm_code(dtype: torch.dtype, x3: bool) -> int:
+    """MFMA compute type of the forward-only kernels: fp32 tensors may ask for the 3 x bf16 product."""
+    return OD_F32X3 if (x3 and dtype == torch.float32) else dt_code(dtype)
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -41,13 +46,13 @@ def _f32(*ts):
 
 
 # ---------------------------------------------------------------- GEMMs
-def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False):
+def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False, x3=False):
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and tuple(C.shape) == (M, N)
     assert A.dtype == W.dtype == C.dtype
     _f32(bias)
-    _lib.lib().od_gemm_nt(dt_code(A.dtype), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
+    _lib.lib().od_gemm_nt(mm_code(A.dtype, x3), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
                           epilogue, int(accumulate), _stream(A))
 
 
@@ -176,9 +181,9 @@ def qk_norm_rope_bwd(qkv, wq, wk, table, dqk, dqkv, dwq, dwk, B, L, H, hd, eps):
                                    _p(dqkv), _ld(dqkv), _p(dwq), _p(dwk), B, L, H, hd, eps, _stream(qkv))
 
 
-def flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale):
+def flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale, x3=False):
     _f32(lse)
-    _lib.lib().od_flash_attn_fwd(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(lse),
+    _lib.lib().od_flash_attn_fwd(mm_code(q.dtype, x3), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(lse),
                                  B, H, L, hd, scale, _stream(q))
 
 

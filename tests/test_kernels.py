@@ -38,6 +38,41 @@ def test_gemm_nt(dev, dtype, M, N, K):
     assert rel_l2(C.float(), ref - b.cpu() + C0.float().cpu()) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (300, 384, 192), (512, 512, 256)])
+def test_gemm_nt_f32x3(dev, M, N, K):
+    """OD_F32X3: fp32 tensors, three bf16 MFMAs per product.  Tolerance 2e-5 rel-L2 against fp64
+    (measured ~4e-6: two dropped terms of 2^-17 relative size each)."""
+    g = torch.Generator().manual_seed(11)
+    A, W, b = mk((M, K), g, dev), mk((N, K), g, dev, scale=0.2), mk((N,), g, dev)
+    C = torch.zeros(M, N, device=dev)
+    ops.gemm_nt(A, W, b, C, x3=True)
+    ref = (A.double().cpu() @ W.double().cpu().t() + b.double().cpu()).float()
+    assert rel_l2(C, ref) < 2e-5
+    C32 = torch.zeros(M, N, device=dev)
+    ops.gemm_nt(A, W, b, C32)
+    assert not torch.equal(C, C32), "the x3 request must reach a different kernel"
+    ops.gemm_nt(A, W, b, C, epilogue=ops.OD_EPI_SILU, x3=True)
+    assert rel_l2(C, O.silu(ref)) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,L,hd", [(1, 2, 150, 32), (1, 1, 257, 64), (2, 1, 64, 64)])
+def test_flash_attention_fwd_f32x3(dev, B, H, L, hd):
+    g = torch.Generator().manual_seed(12)
+    M, dh = B * L, H * hd
+    q, k, v = (mk((M, dh), g, dev) for _ in range(3))
+    o = torch.zeros(M, dh, device=dev)
+    lse = torch.zeros(B, H, L, device=dev)
+    scale = 1 / math.sqrt(hd)
+    ops.flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale, x3=True)
+
+    def heads(t):
+        return t.double().cpu().reshape(B, L, H, hd).permute(0, 2, 1, 3)
+    s = heads(q) @ heads(k).transpose(-1, -2) * scale
+    ref = (torch.softmax(s, -1) @ heads(v)).permute(0, 2, 1, 3).reshape(M, dh).float()
+    assert rel_l2(o, ref) < 2e-5
+    assert rel_l2(lse, torch.logsumexp(s, -1).float()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 136, 72), (64, 16, 24), (1000, 130, 170), (600, 264, 300)])
 def test_gemm_tn_colsum(dev, dtype, M, N, K):

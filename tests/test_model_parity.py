@@ -95,6 +95,18 @@ def run_case(name, dev):
     xs = model.sample(dd["h"], dd["s"], int(fx["num_steps"]), x_init=dd["x_init"])
     assert rel_l2(xs, fx["sample_x"]) < 1e-4
 
+    # ---- fp32 tensors, 3 x bf16 MFMA products (OD_F32X3): held to the same forward / sampler bounds
+    model.f32_matmul = "bf16x3"
+    with torch.no_grad():
+        u3, v3 = model(dd["h"], dd["s"], xt)
+    xs3 = model.sample(dd["h"], dd["s"], int(fx["num_steps"]), x_init=dd["x_init"])
+    model.f32_matmul = "f32"
+    assert not torch.equal(v3, v), "f32_matmul='bf16x3' must reach the f32x3 kernels"
+    assert rel_l2(v3, fx["fwd_v"]) < 5e-5 and rel_l2(u3, fx["fwd_u"]) < 1e-5
+    assert rel_l2(xs3, fx["sample_x"]) < 1e-4
+    print(f"[{name}] f32x3: fwd_v {rel_l2(v3, fx['fwd_v']):.2e} (f32 {rel_l2(v, fx['fwd_v']):.2e}), "
+          f"sampler {rel_l2(xs3, fx['sample_x']):.2e} (f32 {rel_l2(xs, fx['sample_x']):.2e})")
+
     # ---- training loss + gradients through the trainer's forward
     opt_cfg = tr.configure_optimizers()
     opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
