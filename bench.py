@@ -185,6 +185,50 @@ def sampler_bench(device):
     return {"workload": "50-step sampler, B=4, L=1115, audio batch 1 (broadcast), hipGraph", **out}
 
 
+def ldm_bench(device):
+    """Whole inference pipeline, LDM.sample (inference/model.py:34-51) on BASELINE configs[3]'s song: a 3-minute
+    spectrogram (72 x 30093 frames), 4 difficulties, 50 denoiser steps, default model.yml widths.  Stage times from
+    HIP events around each stage on the launch stream."""
+    from osu_dreamer_amd.ldm import LDM
+    a = default_model_args()
+    torch.manual_seed(7)
+    m = LDM(dict(emb_dim=6, style_dim=32, n_downs=3, stride=3,
+                 latent_args=dict(h_dim=128, ae_args=dict(n_layers=8, expand=4, radius=2), style_head_dim=64, style_heads=16),
+                 style_args=dict(label_features=128, h_dim=256, depth=8, expand=4),     # models/style/model.yml
+                 diffusion_args=a["diffusion_args"]))
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():      # tensors the reference zero-initialises: give them small values so no stage is an identity
+        for n, p in m.named_parameters():
+            if float(p.abs().max()) == 0.0:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    m = m.to(device).eval()
+    B, L = 4, 30093
+    audio = torch.randn(72, L, generator=g).to(device)
+    labels = (torch.rand(B, 5, generator=g) * 10).to(device)
+    out = {}
+    for name, dt, mm in (("fp32", None, "f32"), ("fp32_bf16x3", None, "bf16x3"), ("bf16", torch.bfloat16, "f32")):
+        m.set_precision(dt, mm)
+        m.sample(audio, labels, 50)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        from osu_dreamer_amd.ldm import pad_to_multiple
+        t0 = time.time()
+        ev[0].record()
+        ap = pad_to_multiple(audio, m.latent.chunk_size)
+        skips, h = m.latent.audio_encoder(ap[None]); ev[1].record()
+        s_ = m.style.sample(labels); ev[2].record()
+        z = m.diffusion.sample(h, s_, 50); ev[3].record()
+        chart, _ = m.latent.decode(z, s_, skips=skips); ev[4].record()
+        torch.cuda.synchronize()
+        wall = time.time() - t0
+        st = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+        out[name] = {"ms_total": round(wall * 1e3, 2), "charts_per_s": round(B / wall, 2),
+                     "spec_frames_per_s": round(B * L / wall, 1),
+                     "ms_audio_encoder": round(st[0], 2), "ms_style_sampler": round(st[1], 2),
+                     "ms_denoiser_sampler": round(st[2], 2), "ms_decode": round(st[3], 2)}
+    return {"workload": "LDM.sample: 72x30093 spectrogram (3 min), 4 difficulties, 50 steps, default widths", **out}
+
+
 def forward_target_shape(tr, device, B=64, L=8192):
     """north_star's target shape: denoiser FORWARD at batch 64 x 8192 frames, bf16.  Reports the binding
     (MFMA) fraction and, because the target was phrased against HBM, the HBM fraction of the algorithmic
@@ -304,6 +348,7 @@ def main():
             line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
             line["forward_64x8192"] = forward_target_shape(tr, device)
             line["sampler"] = sampler_bench(device)
+            line["ldm_sample"] = ldm_bench(device)
             line["cpu_baseline"] = cpu_baseline()
     else:
         line = None

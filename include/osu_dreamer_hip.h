@@ -188,6 +188,36 @@ int od_style_conditioning(const float* labels, const float* rff_w, const float* 
  * and rms_norm at :99. */
 int od_rmsnorm_rows(const float* x, const float* gamma, float* y, int M, int C, float eps, void* stream);
 
+/* ---- latent model, inference path (models/latent/{spec_features,unet,model}.py; LDM.sample's steps either
+ *      side of diffusion.sample, inference/model.py:48,51).  Frame-major [B*L][C] activations; C = h_dim must be a
+ *      power of two in 8..512.  The SwiGLU body of each block is od_dwconv + od_gemm_nt + od_swiglu_rmsnorm. ---- */
+/* out[(b,l)][c2*3 + a] = SiLU(rms(conv2(SiLU(rms(conv1(audio)) * g1))) * g2): the two strided Conv2d stages of
+ * SpecFeatures with their channel RMS norms, audio (B,72,L) fp32 channel-major.  replaces: spec_features.py:17-26. */
+int od_spec_features_conv(int dtype, const float* audio, const float* w1, const float* b1, const float* g1, const float* w2,
+                          const float* b2, const float* g2, void* out, int ldo, int B, int F, int L, float eps, void* stream);
+/* y = act(rms_norm(x) * gamma * (1 + scale[b]) + shift[b]); ssg = [B][3C] (scale, shift, gate) or NULL.
+ * replaces: unet.py:50 (norm + FiLM), :53 (out_norm), spec_features.py:27-28. */
+int od_rmsnorm_affine_film(int dtype, const void* x, int ldx, const float* gamma, const float* ssg, void* y, int ldy, int B,
+                           int L, int C, float eps, int act, void* stream);
+/* xo = x + rms_norm(h) * gamma * (1 + gate[b]) (gate = ssg[b][2C:3C], 0 when ssg is NULL).  replaces: unet.py:28,51. */
+int od_rmsnorm_affine_gate_residual(int dtype, const void* x, int ldx, const void* h, int ldh, const float* gamma,
+                                    const float* ssg, void* xo, int ldxo, int B, int L, int C, float eps, void* stream);
+/* xo = x + rms_norm(p) * gamma * gx, p = proj(skip) rows (L rows shared by all b when p_bcast), gx = gate(x) rows.
+ * replaces: unet.py:117-126 (mixer). */
+int od_unet_mixer(int dtype, const void* x, int ldx, const void* p, int ldp, int p_bcast, const void* gx, int ldg,
+                  const float* gamma, void* xo, int ldxo, int B, int L, int C, float eps, void* stream);
+/* depthwise Conv1d(k = 1 + 2*(stride/2), zero pad) then AvgPool1d(stride): x [B*Lo*stride][C] -> y [B*Lo][C].
+ * replaces: unet.py:58-63. */
+int od_unet_down(int dtype, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int Lo, int C,
+                 int stride, void* stream);
+/* nearest Upsample(stride) then the same depthwise Conv1d: x [B*Li][C] -> y [B*Li*stride][C].  replaces: unet.py:80-85. */
+int od_unet_up(int dtype, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int Li, int C,
+               int stride, void* stream);
+/* out (B,N,L) fp32 = f_n(bias[n] + W[n] . x[(b,l)]), f_n = sigmoid for n < n_sigmoid else identity (N <= 16).
+ * replaces: latent/model.py:114 (proj_out) + :127-131 (hit-signal sigmoid). */
+int od_chart_head(int dtype, const void* x, int ldx, const float* W, const float* bias, float* out, int B, int L, int C, int N,
+                  int n_sigmoid, void* stream);
+
 /* ---- hipGraph helpers for the captured sampler loop ---------------------------------- */
 int od_graph_begin(void* stream);
 int od_graph_end(void* stream, void** graph_exec_out);

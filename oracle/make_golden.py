@@ -303,6 +303,104 @@ def gen_style(out_dir, name, d, B, seed):
     print(name, "u", u.tolist()[:3])
 
 
+def gen_latent(out_dir, name, d, B, Ba, L, seed):
+    """Latent-model inference-path fixtures from the reference's LatentModel (models/latent/model.py):
+    audio_encoder -> (skips, h) and decode(z, s, skips=...) -> (chart, labels)."""
+    from oracle import latent_oracle as LO
+    from osu_dreamer.models.latent.model import LatentModel, LatentModelArgs
+    from osu_dreamer.models.latent.unet import LayerArgs
+    P = LO.init_latent_params(d, seed)
+    m = LatentModel(d.emb_dim, d.style_dim, d.n_downs, d.stride,
+                    LatentModelArgs(h_dim=d.h_dim, ae_args=LayerArgs(n_layers=d.n_layers, expand=d.expand, radius=d.radius),
+                                    style_head_dim=8, style_heads=2))
+    sd = m.state_dict()
+    for k, w in P.items():
+        assert k in sd and tuple(sd[k].shape) == tuple(w.shape), k
+    on_path = ("audio_encoder.", "proj_emb.", "decoder.", "proj_out.", "label_predictor.")
+    assert sorted(k for k in sd if k.startswith(on_path)) == sorted(P.keys())
+    res = m.load_state_dict(P, strict=False)
+    assert not res.unexpected_keys and all(not k.startswith(on_path) for k in res.missing_keys)
+    m.eval()
+    assert L % d.chunk_size == 0
+    g = torch.Generator().manual_seed(seed + 1)
+    audio = torch.randn(Ba, LO.A_DIM, L, generator=g)
+    z = torch.randn(B, d.emb_dim, L // d.chunk_size, generator=g)
+    z = z * z.pow(2).mean(1, keepdim=True).add(1e-6).rsqrt()
+    s = torch.randn(B, d.style_dim, generator=g)
+    s = s * s.pow(2).mean(1, keepdim=True).add(1e-6).rsqrt()
+    with torch.no_grad():
+        skips, h = m.audio_encoder(audio)
+        feat = m.audio_encoder[0](audio)
+        chart, labels = m.decode(z, s, skips=list(skips))
+        chart2, _ = m.decode(z, s, audio=audio)
+        assert torch.equal(chart, chart2)
+        # the restatement against the reference, on the spot
+        o_skips, o_h = LO.audio_encoder(P, audio, d)
+        o_chart, o_labels = LO.decode(P, z, s, o_skips, d)
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+    assert rel(o_h, h) < 2e-6 and rel(o_chart, chart) < 2e-6 and rel(o_labels, labels) < 2e-6, (rel(o_h, h), rel(o_chart, chart))
+    fx = {"dims": np.array([d.emb_dim, d.style_dim, d.n_downs, d.stride, d.h_dim, d.n_layers, d.expand, d.radius]),
+          "seed": seed, "audio": audio, "z": z, "s": s, "feat": feat, "h": h, "chart": chart, "labels": labels}
+    for i, sk in enumerate(skips):
+        fx[f"skip{i}"] = sk
+    if d.h_dim <= 64:
+        for k, w in P.items():
+            fx["w." + k] = w
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
+    print(name, "oracle-vs-reference", rel(o_h, h), rel(o_chart, chart))
+
+
+def gen_ldm(out_dir, name, ld, sd_, dd, B, L, num_steps, seed):
+    """End-to-end fixture from the reference's LDM.sample (models/inference/model.py:34-51): audio (72, L) and
+    labels in, chart and labels out, with the two samplers' initial noise pinned (th.randn is one torch
+    function shared by both model modules, so it is patched once and answers by requested shape)."""
+    from oracle import latent_oracle as LO, style_oracle as SO
+    from osu_dreamer.models.inference.model import LDM, LDMArgs
+    from osu_dreamer.models.latent.model import LatentModelArgs
+    from osu_dreamer.models.latent.unet import LayerArgs
+    from osu_dreamer.models.style.model import StyleModelArgs
+    from osu_dreamer.models.diffusion.model import DiffusionModelArgs
+    from osu_dreamer.models.diffusion.backbone import BackboneArgs
+    assert dd.a_dim == ld.h_dim and dd.style_dim == ld.style_dim == sd_.style_dim and dd.emb_dim == ld.emb_dim
+    PL, PS, PD = LO.init_latent_params(ld, seed), SO.init_style_params(sd_, seed + 1), O.init_params(dd, seed=seed + 2)
+    m = LDM(LDMArgs(
+        emb_dim=ld.emb_dim, style_dim=ld.style_dim, n_downs=ld.n_downs, stride=ld.stride,
+        latent_args=LatentModelArgs(h_dim=ld.h_dim, ae_args=LayerArgs(ld.n_layers, ld.expand, ld.radius), style_head_dim=8, style_heads=2),
+        style_args=StyleModelArgs(label_features=sd_.label_features, h_dim=sd_.h_dim, depth=sd_.depth, expand=sd_.expand),
+        diffusion_args=DiffusionModelArgs(global_cond_dim=dd.global_cond_dim, backbone_dim=dd.backbone_dim, u_head_dim=dd.u_head_dim,
+                                          backbone_args=BackboneArgs(depth=dd.depth, expand=dd.expand, head_dim=dd.head_dim,
+                                                                     n_heads=dd.n_heads, radius=dd.radius))))
+    full = {**{"latent." + k: v for k, v in PL.items()}, **{"style." + k: v for k, v in PS.items()},
+            **{"diffusion." + k: v for k, v in PD.items()}}
+    res = m.load_state_dict(full, strict=False)
+    assert not res.unexpected_keys
+    assert all(k.startswith(("latent.chart_encoder.", "latent.style_head.", "latent.temporal_")) for k in res.missing_keys)
+    m.eval()
+    g = torch.Generator().manual_seed(seed + 3)
+    audio = torch.randn(LO.A_DIM, L, generator=g)
+    labels = torch.rand(B, 5, generator=g) * 10
+    labels[0, 2] = -1.0
+    Lp = (L + ld.chunk_size - 1) // ld.chunk_size * ld.chunk_size
+    s_init = torch.randn(B, ld.style_dim, generator=g)
+    x_init = torch.randn(B, ld.emb_dim, Lp // ld.chunk_size, generator=g)
+    by_shape = {tuple(s_init.shape): s_init, tuple(x_init.shape): x_init}
+    saved = torch.randn
+    torch.randn = lambda *a, **k: by_shape[tuple(a[0]) if len(a) == 1 and not isinstance(a[0], int) else tuple(a)].clone()
+    try:
+        chart, out_labels = m.sample(audio, labels, num_steps)
+    finally:
+        torch.randn = saved
+    fx = {"ldims": np.array([ld.emb_dim, ld.style_dim, ld.n_downs, ld.stride, ld.h_dim, ld.n_layers, ld.expand, ld.radius]),
+          "sdims": np.array([sd_.style_dim, sd_.label_features, sd_.h_dim, sd_.depth, sd_.expand]),
+          "ddims": np.array([dd.emb_dim, dd.a_dim, dd.style_dim, dd.global_cond_dim, dd.backbone_dim, dd.n_heads, dd.head_dim,
+                             dd.depth, dd.expand, dd.radius, dd.u_head_dim]),
+          "seed": seed, "num_steps": num_steps, "audio": audio, "labels": labels, "s_init": s_init, "x_init": x_init,
+          "chart": chart, "out_labels": out_labels}
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
+    print(name, "chart", tuple(chart.shape), float(chart.abs().mean()))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -312,9 +410,22 @@ def main():
     gen_lr(out_dir)
     gen_ops(out_dir)
     from oracle import style_oracle as SO
-    gen_style(out_dir, "style_tiny", SO.STYLE_TINY, B=3, seed=500)
-    gen_style(out_dir, "style_full", SO.STYLE_FULL, B=4, seed=600)
+    if os.environ.get("GOLDEN_ONLY") != "latent":
+        gen_style(out_dir, "style_tiny", SO.STYLE_TINY, B=3, seed=500)
+        gen_style(out_dir, "style_full", SO.STYLE_FULL, B=4, seed=600)
     if os.environ.get("GOLDEN_ONLY") == "style":
+        return
+    from oracle import latent_oracle as LO
+    gen_latent(out_dir, "latent_tiny", LO.LATENT_TINY, B=3, Ba=1, L=9 * 7, seed=700)
+    gen_latent(out_dir, "latent_tiny_b2", LO.LATENT_TINY, B=2, Ba=2, L=9 * 5, seed=710)
+    gen_latent(out_dir, "latent_full", LO.LATENT_FULL, B=2, Ba=1, L=27 * 6, seed=720)
+    # whole pipeline, LDM.sample: tiny widths (weights regenerated from the seed on both sides) and the default
+    # model.yml widths with a depth-2 denoiser, on a spectrogram whose length needs padding
+    gen_ldm(out_dir, "ldm_tiny", LO.LatentDims(style_dim=8, n_downs=2, h_dim=32, n_layers=2), SO.STYLE_TINY,
+            O.Dims(emb_dim=6, a_dim=32, style_dim=8, global_cond_dim=32, backbone_dim=64, n_heads=2, head_dim=32, depth=2,
+                   expand=4, radius=2, u_head_dim=16), B=3, L=9 * 6 + 4, num_steps=6, seed=800)
+    gen_ldm(out_dir, "ldm_full_d2", LO.LATENT_FULL, SO.STYLE_FULL, O.Dims(depth=2), B=2, L=27 * 5 + 11, num_steps=4, seed=810)
+    if os.environ.get("GOLDEN_ONLY") == "latent":
         return
     # tiny config: weights + every gradient stored (a few hundred KB)
     gen_model(out_dir, "tiny_b3_l40", O.TINY, B=3, L=40, seed=100, store_weights=True, with_bf16=True)

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libosudreamer_hip.so
-SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip style.hip"
+SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip style.hip latent.hip"
 OBJS=""
 mkdir -p build
 for s in $SRCS; do

@@ -323,3 +323,48 @@ def rmsnorm_rows(x, gamma, y, eps):
     M, C = x.shape
     _f32(x, gamma, y)
     _lib.lib().od_rmsnorm_rows(_p(x), _p(gamma), _p(y), M, C, eps, _stream(x))
+
+
+# ---------------------------------------------------------------- latent model, inference path
+def spec_features_conv(audio, w1, b1, g1, w2, b2, g2, out, eps=1e-6):
+    B, F, L = audio.shape
+    _f32(audio, w1, b1, g1, w2, b2, g2)
+    _lib.lib().od_spec_features_conv(dt_code(out.dtype), _p(audio), _p(w1), _p(b1), _p(g1), _p(w2), _p(b2), _p(g2),
+                                     _p(out), _ld(out), B, F, L, eps, _stream(audio))
+
+
+def rmsnorm_affine_film(x, gamma, ssg, y, B, L, act=OD_ACT_NONE, eps=1e-6):
+    _f32(gamma, ssg)
+    _lib.lib().od_rmsnorm_affine_film(dt_code(x.dtype), _p(x), _ld(x), _p(gamma), _p(ssg), _p(y), _ld(y), B, L, x.shape[1],
+                                      eps, act, _stream(x))
+
+
+def rmsnorm_affine_gate_residual(x, h, gamma, ssg, xo, B, L, eps=1e-6):
+    _f32(gamma, ssg)
+    _lib.lib().od_rmsnorm_affine_gate_residual(dt_code(x.dtype), _p(x), _ld(x), _p(h), _ld(h), _p(gamma), _p(ssg), _p(xo),
+                                               _ld(xo), B, L, x.shape[1], eps, _stream(x))
+
+
+def unet_mixer(x, p, p_bcast, gx, gamma, xo, B, L, eps=1e-6):
+    _f32(gamma)
+    _lib.lib().od_unet_mixer(dt_code(x.dtype), _p(x), _ld(x), _p(p), _ld(p), int(p_bcast), _p(gx), _ld(gx), _p(gamma),
+                             _p(xo), _ld(xo), B, L, x.shape[1], eps, _stream(x))
+
+
+def unet_down(x, w, bias, y, B, Lo, stride):
+    _f32(w, bias)
+    _lib.lib().od_unet_down(dt_code(x.dtype), _p(x), _ld(x), _p(w), _p(bias), _p(y), _ld(y), B, Lo, x.shape[1], stride,
+                            _stream(x))
+
+
+def unet_up(x, w, bias, y, B, Li, stride):
+    _f32(w, bias)
+    _lib.lib().od_unet_up(dt_code(x.dtype), _p(x), _ld(x), _p(w), _p(bias), _p(y), _ld(y), B, Li, x.shape[1], stride,
+                          _stream(x))
+
+
+def chart_head(x, W, bias, out, B, L, n_sigmoid):
+    _f32(W, bias, out)
+    N = W.shape[0]
+    _lib.lib().od_chart_head(dt_code(x.dtype), _p(x), _ld(x), _p(W), _p(bias), _p(out), B, L, x.shape[1], N, n_sigmoid,
+                             _stream(x))

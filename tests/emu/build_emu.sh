@@ -6,7 +6,7 @@ CS=../../osu_dreamer_amd/csrc
 OUT=libod_emu.so
 mkdir -p build
 OBJS=""
-for s in gemm rowops misc heads optim attn style; do
+for s in gemm rowops misc heads optim attn style latent; do
   o=build/$s.o
   if [ ! -f "$o" ] || [ "$CS/$s.hip" -nt "$o" ] || [ "$CS/od_common.h" -nt "$o" ] || [ "$CS/od_tiles.h" -nt "$o" ] || [ emu_hip.h -nt "$o" ]; then
     /opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fPIC -DOD_EMU -DOD_GEMM_BIG_MIN_M=256 -I. -I$CS -Wno-unused-value -c $CS/$s.hip -o $o &

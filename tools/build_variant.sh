@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../osu_dreamer_amd/csrc"
 name=$1; flags=$2
 out=../../gpurun_variants; mkdir -p $out/obj_$name
-for s in gemm rowops misc heads optim attn style; do
+for s in gemm rowops misc heads optim attn style latent; do
   extra=""; [ "$s" = "attn" ] && extra="-ffinite-math-only $ATTN_FLAGS"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra $flags -c $s.hip -o $out/obj_$name/$s.o &
 done
