@@ -90,6 +90,12 @@ int od_rmsnorm_film_bwd(int dtype, const void* x, int ldx, const float* inv_rms,
 /* xo = x + rms_norm(h)*gate[b];  inv_rms[m] saved.  replaces: backbone.py:79-80,85-86. */
 int od_rmsnorm_gate_residual(int dtype, const void* x, int ldx, const void* h, int ldh, const float* ssg, void* xo,
                              int ldxo, float* inv_rms, int B, int L, int C, float eps, void* stream);
+/* the pair above fused for the forward pass: xo = x + rms_norm(h) * gate_a, then
+ * h2 = rms_norm(xo) * (1 + scale_b) + shift_b (+ cl) — one pass over the frame instead of two
+ * (identical results: xo is rounded to dtype before the second norm).  replaces: backbone.py:78-86. */
+int od_rmsnorm_gate_residual_film(int dtype, const void* x, int ldx, const void* h, int ldh, const float* ssg_a, void* xo, int ldxo,
+                                  float* inv_a, const float* ssg_b, const void* cl, int ldcl, int cl_bcast, void* h2, int ldh2,
+                                  float* inv_b, int B, int L, int C, float eps, void* stream);
 /* dh = rms_norm_bwd(dy*gate); dssg[b][2C:3C] += sum dy*hhat.  (dy itself is the residual gradient.) */
 int od_rmsnorm_gate_residual_bwd(int dtype, const void* h, int ldh, const float* inv_rms, const float* ssg,
                                  const void* dy, int lddy, void* dh, int lddh, float* dssg, int B, int L, int C,

@@ -47,20 +47,20 @@ __device__ __forceinline__ void frag_from_lds<f32x3_t>(od_frag<f32x3_t>& f, cons
 }
 
 // One 128-byte-deep slab of MFMAs from a staged (A,B) pair.
-template <class T>
+template <class T, int WMT>
 __device__ __forceinline__ void compute_stage(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
-                                              f32x4 (&acc)[4][4]) {
+                                              f32x4 (&acc)[WMT][4]) {
     constexpr int SLABS = (128 / (int)sizeof(T)) / 32;
     const int r16 = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int s = 0; s < SLABS; s++) {
-        od_frag<T> fa[4], fb[4];
+        od_frag<T> fa[WMT], fb[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) frag_from_lds<T>(fa[i], sA, wm * 64 + i * 16 + r16, s, g);
+        for (int i = 0; i < WMT; i++) frag_from_lds<T>(fa[i], sA, wm * 16 * WMT + i * 16 + r16, s, g);
 #pragma unroll
         for (int j = 0; j < 4; j++) frag_from_lds<T>(fb[j], sB, wn * 64 + j * 16 + r16, s, g);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < WMT; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = od_mma(fa[i], fb[j], acc[i][j]);
     }
@@ -77,7 +77,9 @@ __device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int& tm,
     return tm < tiles_m;
 }
 
-template <class T, int EPI, bool DMA>
+// WMT = 16-row MFMA tiles per wave along m: 4 -> 128 x 128 block tile, 2 -> 64 x 128 (twice the workgroups, for
+// launches whose 128-row tiling would leave CUs idle: the sampler's M = B*L = 4460 against N = 512)
+template <class T, int EPI, bool DMA, int WMT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                       const float* __restrict__ bias, T* __restrict__ C, int ldc,
                                                       int M, int N, int K, int accumulate) {
@@ -85,16 +87,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
     constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
 
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    constexpr int BMT = 32 * WMT;
+    const int tiles_m = (M + BMT - 1) / BMT, tiles_n = (N + BN - 1) / BN;
     int tm, tn;
     if (!tile_of_block(tiles_m, tiles_n, tm, tn)) return;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BMT, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    f32x4 acc[4][4];
+    f32x4 acc[WMT][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < WMT; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4)(0.f);
 
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
             int ar = m0 + row; ar = ar < M ? ar : M - 1;
             int br = n0 + row; br = br < N ? br : N - 1;
             if (k < K) {
-                ra[i] = *(const u32x4*)(A + (size_t)ar * lda + k);
+                if (i < WMT) ra[i] = *(const u32x4*)(A + (size_t)ar * lda + k);
                 rb[i] = *(const u32x4*)(W + (size_t)br * ldw + k);
             } else {
                 ra[i] = (u32x4)(0u); rb[i] = (u32x4)(0u);
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
-            *(u32x4*)(sA + swz(row, slot)) = ra[i];
+            if (i < WMT) *(u32x4*)(sA + swz(row, slot)) = ra[i];
             *(u32x4*)(sB + swz(row, slot)) = rb[i];
         }
     };
@@ -138,10 +141,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
                 const int row = (wave * 4 + i) * 8 + (lane >> 3);
                 const int slot = (lane & 7) ^ (row & 7);
                 const int k = kt * BK + slot * CH;
-                int ar = m0 + row; ar = ar < M ? ar : M - 1;
                 int br = n0 + row; br = br < N ? br : N - 1;
-                od_glds16(A + (size_t)ar * lda + k, sA + (wave * 4 + i) * 1024 + lane * 16);
                 od_glds16(W + (size_t)br * ldw + k, sB + (wave * 4 + i) * 1024 + lane * 16);
+                if (i < WMT) {
+                    const int rowa = (wave * WMT + i) * 8 + (lane >> 3);     // same (row & 7), hence the same slot
+                    int ar = m0 + rowa; ar = ar < M ? ar : M - 1;
+                    od_glds16(A + (size_t)ar * lda + k, sA + (wave * WMT + i) * 1024 + lane * 16);
+                }
             }
         };
         dma(0, 0);
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         for (int kt = 0; kt < nk; kt++) {
             const int buf = kt & 1;
             if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
-            compute_stage<T>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+            compute_stage<T, WMT>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
             __syncthreads();
         }
     } else {
@@ -159,28 +165,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        compute_stage<T>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+        compute_stage<T, WMT>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
     }
 
-    // epilogue: accumulators -> LDS (f32 [128][128]) -> coalesced row stores
+    // epilogue: accumulators -> LDS (f32 [BMT][128]) -> coalesced row stores
     float* sC = (float*)smem;
     {
         const int col = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < WMT; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    sC[(wm * 64 + i * 16 + g * 4 + r) * 128 + wn * 64 + j * 16 + col] = acc[i][j][r];
+                    sC[(wm * 16 * WMT + i * 16 + g * 4 + r) * 128 + wn * 64 + j * 16 + col] = acc[i][j][r];
     }
     __syncthreads();
     const bool vec_ok = (N % 8 == 0) && (ldc % 8 == 0);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 2 * WMT; i++) {
         const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
         const int gm = m0 + row, gn = n0 + ch * 8;
         if (gm >= M || gn >= N) continue;
@@ -606,7 +612,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ G, in
 template <class T>
 int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C, int ldc, int M, int N, int K, int epi,
               int accumulate, hipStream_t st) {
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int tiles_n = (N + BN - 1) / BN;
+#ifndef OD_GEMM_SMALL_TILES
+#define OD_GEMM_SMALL_TILES 512     // fewer 128-row tiles than 2 per CU: use 64-row tiles (the emulator build lowers it)
+#endif
+    const bool half = ((M + 127) / 128) * tiles_n < OD_GEMM_SMALL_TILES;
+    const int tiles_m = half ? (M + 63) / 64 : (M + 127) / 128;
     const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const bool dma = (K % (128 / (int)sizeof(T))) == 0;
     if (dma && M >= OD_GEMM_BIG_MIN_M && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
@@ -619,13 +630,15 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
         OD_CHECK_LAUNCH();
         return 0;
     }
+#define NT_GO(EPI_, DMA_, WMT_) OD_LAUNCH((gemm_nt_kernel<T, EPI_, DMA_, WMT_>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate)
+#define NT_GO2(EPI_, DMA_) do { if (half) NT_GO(EPI_, DMA_, 2); else NT_GO(EPI_, DMA_, 4); } while (0)
     if (epi == OD_EPI_SILU) {
-        if (dma) OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_SILU, true>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
-        else OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_SILU, false>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+        if (dma) NT_GO2(OD_EPI_SILU, true); else NT_GO2(OD_EPI_SILU, false);
     } else {
-        if (dma) OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_NONE, true>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
-        else OD_LAUNCH((gemm_nt_kernel<T, OD_EPI_NONE, false>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+        if (dma) NT_GO2(OD_EPI_NONE, true); else NT_GO2(OD_EPI_NONE, false);
     }
+#undef NT_GO2
+#undef NT_GO
     OD_CHECK_LAUNCH();
     return 0;
 }

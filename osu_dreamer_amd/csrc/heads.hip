@@ -69,7 +69,7 @@ __device__ __forceinline__ void uhead_load_w4(UHeadSmem& S, const UHeadW& P, int
 }
 
 __global__ __launch_bounds__(256) void uhead_fwd_kernel(const float* __restrict__ xt, UHeadW P, float* __restrict__ fsum,
-                                                        int E, int L, int U, int nwin) {
+                                                        int E, int L, int U, int nwin, int wpb) {
     __shared__ UHeadSmem S;
     const int b = blockIdx.y, t = threadIdx.x;
     const int i = t & 31, grp = t >> 5, cpg = U / 8;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void uhead_fwd_kernel(const float* __restrict_
     float acc[MAXU / 8];
 #pragma unroll
     for (int q = 0; q < MAXU / 8; q++) acc[q] = 0.f;
-    for (int wi = 0; wi < UWPB; wi++) {
-        const int win = blockIdx.x * UWPB + wi;
+    for (int wi = 0; wi < wpb; wi++) {
+        const int win = blockIdx.x * wpb + wi;
         if (win >= nwin) break;
         const int l0 = win * UOWN;
         uhead_window_fwd(S, xt, P, b, l0, E, L, U);
@@ -386,7 +386,10 @@ extern "C" int od_uhead_fwd(const float* xt, const float* w0, const float* b0, c
     if (U > MAXU || U % 8 || E > MAXE) return OD_ERR_UNSUPPORTED;
     const int nwin = (L + UOWN - 1) / UOWN;
     UHeadW P{w0, b0, w1, b1, w3, b3, w4, b4};
-    OD_LAUNCH(uhead_fwd_kernel, dim3((nwin + UWPB - 1) / UWPB, B), dim3(256), 0, (hipStream_t)stream, xt, P, fsum, E, L, U, nwin);
+    // windows a block walks: up to UWPB for long sequences, fewer when that would leave CUs idle (sampler: L ~ 1e3)
+    int wpb = (int)((long)nwin * B / 512);
+    wpb = wpb < 1 ? 1 : (wpb > UWPB ? UWPB : wpb);
+    OD_LAUNCH(uhead_fwd_kernel, dim3((nwin + wpb - 1) / wpb, B), dim3(256), 0, (hipStream_t)stream, xt, P, fsum, E, L, U, nwin, wpb);
     OD_CHECK_LAUNCH();
     return 0;
 }

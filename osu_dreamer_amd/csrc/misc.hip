@@ -114,8 +114,9 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const T* __restrict__ x, 
 
 // ------------------------------------------------------------ depthwise conv along frames
 // thread = 8 channels x a run of RUN frames, sliding a K-tap register window down the frames.
-constexpr int DW_RUN = 32;
-template <class T, int KS>
+// RUN = 32 for long sequences (halo re-read 1.125x); short workloads (the sampler's B*L = 4460 frames) use
+// RUN = 4 so the launch still covers the chip (the halo re-reads hit L2).
+template <class T, int KS, int DW_RUN>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ bias, T* __restrict__ y, int ldy,
                                                      int L, int C) {
@@ -352,7 +353,8 @@ extern "C" int od_proj_in(int dtype, const float* xt, const float* W, const floa
     if (E > 8) return OD_ERR_UNSUPPORTED;
     if (D % 8 || ldx % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
-    int blocks = (int)((M + 3) / 4); if (blocks > 4096) blocks = 4096;
+    // a thread loads its 8 x E weights once and then streams frames: give every wave >= 4 frames
+    int blocks = (int)((M + 15) / 16); if (blocks > 4096) blocks = 4096;
     DISPATCH_T(dtype, OD_LAUNCH((proj_in_kernel<T_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, xt, W, bias, (T_*)x, ldx, B, E, L, D));
     OD_CHECK_LAUNCH();
     return 0;
@@ -387,11 +389,18 @@ extern "C" int od_silu_bwd(int dtype, const void* x, const void* dy, void* dx, l
 extern "C" int od_dwconv(int dtype, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int L,
                          int C, int ksize, void* stream) {
     if (C % 8 || ldx % 8 || ldy % 8) return OD_ERR_ALIGN;
-    const long threads = (long)(C / 8) * ((L + DW_RUN - 1) / DW_RUN);
+    if (ksize != 3 && ksize != 5) return OD_ERR_UNSUPPORTED;
+#ifndef OD_DW_SMALL_THREADS
+#define OD_DW_SMALL_THREADS 131072      // < 2 workgroups per CU at RUN = 32 (the emulator build lowers it to reach both paths)
+#endif
+    const bool small = (long)B * (C / 8) * ((L + 31) / 32) < OD_DW_SMALL_THREADS;
+    const int run = small ? 4 : 32;
+    const long threads = (long)(C / 8) * ((L + run - 1) / run);
     dim3 grid((unsigned)((threads + 255) / 256), B);
-    if (ksize == 5) DISPATCH_T(dtype, OD_LAUNCH((dwconv_kernel<T_, 5>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, bias, (T_*)y, ldy, L, C));
-    else if (ksize == 3) DISPATCH_T(dtype, OD_LAUNCH((dwconv_kernel<T_, 3>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, bias, (T_*)y, ldy, L, C));
-    else return OD_ERR_UNSUPPORTED;
+#define DW_GO(KS_, RUN_) DISPATCH_T(dtype, OD_LAUNCH((dwconv_kernel<T_, KS_, RUN_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, bias, (T_*)y, ldy, L, C))
+    if (ksize == 5) { if (small) DW_GO(5, 4); else DW_GO(5, 32); }
+    else { if (small) DW_GO(3, 4); else DW_GO(3, 32); }
+#undef DW_GO
     OD_CHECK_LAUNCH();
     return 0;
 }

@@ -166,6 +166,63 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_res_kernel(const T* __restri
     }
 }
 
+// fused pair (forward only): xo = x + rms_norm(h) * gate_a, then h2 = rms_norm(xo) * (1 + scale_b) + shift_b (+ cl)
+// — the gate/residual that closes one branch and the norm + FiLM that opens the next (backbone.py:78-86) in
+// one pass over the frame.  xo is rounded to T before the second norm, so the result equals the two-kernel path.
+template <class T, int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_gate_res_film_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ h, int ldh,
+                                                                    const float* __restrict__ ssg_a, T* __restrict__ xo, int ldxo,
+                                                                    float* __restrict__ inv_a, const float* __restrict__ ssg_b,
+                                                                    const T* __restrict__ cl, int ldcl, int cl_bcast,
+                                                                    T* __restrict__ h2, int ldh2, float* __restrict__ inv_b,
+                                                                    int B, int L, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)B * L) return;
+    const int b = (int)(m / L), l = (int)(m % L);
+    float v[NCH][8];
+    load_row<T, NCH>(h + m * ldh, C, lane, v);
+    const float inv = rsqrtf(row_sumsq<NCH>(v) / (float)C + eps);
+    if (lane == 0 && inv_a) inv_a[m] = inv;
+    const float* gate = ssg_a + (size_t)b * 3 * C + 2 * C;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+        if (c >= C) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[i][e] = 0.f;
+            continue;
+        }
+        float g[8], o[8];
+        od_ld8(gate + c, g);
+        od_ld8(x + m * ldx + c, o);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] += v[i][e] * inv * g[e];
+        od_st8(xo + m * ldxo + c, o);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[i][e] = od_round_to<T>(o[e]);
+    }
+    const float inv2 = rsqrtf(row_sumsq<NCH>(v) / (float)C + eps);
+    if (lane == 0 && inv_b) inv_b[m] = inv2;
+    const float* sc = ssg_b + (size_t)b * 3 * C;
+    const T* clrow = cl ? cl + (size_t)(cl_bcast ? l : m) * ldcl : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const int c = (lane + 64 * i) * 8;
+        if (c >= C) continue;
+        float s2[8], sh[8], o[8];
+        od_ld8(sc + c, s2); od_ld8(sc + C + c, sh);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = v[i][e] * inv2 * (1.f + s2[e]) + sh[e];
+        if (clrow) {
+            float a[8]; od_ld8(clrow + c, a);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] += a[e];
+        }
+        od_st8(h2 + m * ldh2 + c, o);
+    }
+}
+
 template <class T, int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_gate_res_bwd_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ inv_rms,
                                                                    const float* __restrict__ ssg, const T* __restrict__ dy, int lddy,
@@ -712,6 +769,19 @@ extern "C" int od_rmsnorm_gate_residual(int dtype, const void* x, int ldx, const
     DISPATCH_T_NCH(dtype, nch_for(C),
         OD_LAUNCH((rmsnorm_gate_res_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, (const T_*)h, ldh, ssg,
                   (T_*)xo, ldxo, inv_rms, B, L, C, eps));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_rmsnorm_gate_residual_film(int dtype, const void* x, int ldx, const void* h, int ldh, const float* ssg_a, void* xo,
+                                             int ldxo, float* inv_a, const float* ssg_b, const void* cl, int ldcl, int cl_bcast,
+                                             void* h2, int ldh2, float* inv_b, int B, int L, int C, float eps, void* stream) {
+    if (C % 8 || ldx % 8 || ldh % 8 || ldxo % 8 || ldh2 % 8 || (cl && ldcl % 8)) return OD_ERR_ALIGN;
+    const long M = (long)B * L;
+    dim3 grid((unsigned)((M + 3) / 4));
+    DISPATCH_T_NCH(dtype, nch_for(C),
+        OD_LAUNCH((rmsnorm_gate_res_film_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, (const T_*)h, ldh,
+                  ssg_a, (T_*)xo, ldxo, inv_a, ssg_b, (const T_*)cl, ldcl, cl_bcast, (T_*)h2, ldh2, inv_b, B, L, C, eps));
     OD_CHECK_LAUNCH();
     return 0;
 }

@@ -177,17 +177,21 @@ class DenoiserEngine:
         bcast = self.Ba == 1 and B > 1
         x = self.lbuf("x_in", 0, (M, D))
         ops.proj_in(xt, self.P("proj_in.weight"), self.P("proj_in.bias"), x)
+
+        def cl_of(i):
+            if not self.train:
+                return self.ws.t[f"cl.{i}"]
+            cl = self.buf("cl", (self.Ma, D))                      # consumed by the FiLM right after: one buffer
+            ops.gemm_nt(self.ws.t["a"], self.W(f"net.layers.{i}.proj_cl"), self.P(f"net.layers.{i}.proj_cl.bias"), cl)
+            return cl
+
+        h1 = self.lbuf("h1", 0, (M, D))
+        ops.rmsnorm_film(x, self.ws.t["ssg1.0"], cl_of(0), bcast, h1, self.lbuf("inv1", 0, (M,), f32), B, L)
         for i in range(self.depth):
             p = f"net.layers.{i}."
             ssg1, ssg2 = self.ws.t[f"ssg1.{i}"], self.ws.t[f"ssg2.{i}"]
-            if self.train:
-                cl = self.buf("cl", (self.Ma, D))
-                ops.gemm_nt(self.ws.t["a"], self.W(p + "proj_cl"), self.P(p + "proj_cl.bias"), cl, x3=self.x3)
-            else:
-                cl = self.ws.t[f"cl.{i}"]
-            # --- attention branch (backbone.py:76-80, attn.py:74-84)
-            h1 = self.lbuf("h1", i, (M, D))
-            ops.rmsnorm_film(x, ssg1, cl, bcast, h1, self.lbuf("inv1", i, (M,), f32), B, L)
+            # --- attention branch (backbone.py:76-80, attn.py:74-84); h1 = norm + FiLM + proj_cl(a) came from the
+            #     kernel that closed the previous layer
             qkv = self.lbuf("qkv", i, (M, 3 * dh))
             ops.gemm_nt(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv, x3=self.x3)
             qk = self.lbuf("qk", i, (M, 2 * dh))
@@ -199,11 +203,12 @@ class DenoiserEngine:
                                1.0 / math.sqrt(self.hd), x3=self.x3)
             ao = self.lbuf("ao", i, (M, D))
             ops.gemm_nt(y, self.W(p + "attn.out_proj"), self.P(p + "attn.out_proj.bias"), ao, x3=self.x3)
+            # --- gate + residual of the attention branch and norm + FiLM of the feed-forward branch, one pass
             x_mid = self.lbuf("x_mid", i, (M, D))
-            ops.rmsnorm_gate_residual(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), B, L)
-            # --- feed-forward branch (backbone.py:82-86, swiglu.py:27-32)
             h2 = self.lbuf("h2", i, (M, D))
-            ops.rmsnorm_film(x_mid, ssg2, None, False, h2, self.lbuf("inv3", i, (M,), f32), B, L)
+            ops.rmsnorm_gate_residual_film(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), ssg2, None, False, h2,
+                                           self.lbuf("inv3", i, (M,), f32), B, L)
+            # --- feed-forward branch (backbone.py:82-86, swiglu.py:27-32)
             hdw = self.lbuf("hdw", i, (M, D))
             ops.dwconv(h2, self.P(p + "ffn.proj_vg.0.weight"), self.P(p + "ffn.proj_vg.0.bias"), hdw, B, L, self.ksize)
             vg = self.lbuf("vg", i, (M, 2 * Hp))
@@ -212,9 +217,15 @@ class DenoiserEngine:
             ops.swiglu_rmsnorm(vg, hh, self.lbuf("inv4", i, (M,), f32), self.Hf, Hp)
             fo = self.lbuf("fo", i, (M, D))
             ops.gemm_nt(hh, self.W(p + "ffn.proj_o"), self.P(p + "ffn.proj_o.bias"), fo, x3=self.x3)
-            # next layer input; at inference x_in.0 / x_in.1 ping-pong
+            # next layer input (at inference x_in.0 / x_in.1 ping-pong), together with the next layer's h1
             x = self.buf(f"x_in.{i + 1}", (M, D)) if self.train else self.buf(f"x_in.{(i + 1) & 1}", (M, D))
-            ops.rmsnorm_gate_residual(x_mid, fo, ssg2, x, self.lbuf("inv5", i, (M,), f32), B, L)
+            if i + 1 < self.depth:
+                h1 = self.lbuf("h1", i + 1, (M, D))
+                ops.rmsnorm_gate_residual_film(x_mid, fo, ssg2, x, self.lbuf("inv5", i, (M,), f32),
+                                               self.ws.t[f"ssg1.{i + 1}"], cl_of(i + 1), bcast, h1,
+                                               self.lbuf("inv1", i + 1, (M,), f32), B, L)
+            else:
+                ops.rmsnorm_gate_residual(x_mid, fo, ssg2, x, self.lbuf("inv5", i, (M,), f32), B, L)
         self._x_last = x
         ops.final_norm_proj_out(x, self.P("proj_out.weight"), self.P("proj_out.bias"), v,
                                 self.buf("invf", (M,), f32), B, L)

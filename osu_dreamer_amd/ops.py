@@ -156,6 +156,14 @@ def rmsnorm_gate_residual(x, h, ssg, xo, inv_rms, B, L, eps=1e-6):
                                         _p(inv_rms), B, L, C, eps, _stream(x))
 
 
+def rmsnorm_gate_residual_film(x, h, ssg_a, xo, inv_a, ssg_b, cl, cl_bcast, h2, inv_b, B, L, eps=1e-6):
+    """xo = x + rms(h) * gate_a;  h2 = rms(xo) * (1 + scale_b) + shift_b (+ cl)  — forward-only fused pair."""
+    _f32(ssg_a, ssg_b, inv_a, inv_b)
+    _lib.lib().od_rmsnorm_gate_residual_film(dt_code(x.dtype), _p(x), _ld(x), _p(h), _ld(h), _p(ssg_a), _p(xo), _ld(xo),
+                                             _p(inv_a), _p(ssg_b), _p(cl), _ld(cl) if cl is not None else 0, int(cl_bcast),
+                                             _p(h2), _ld(h2), _p(inv_b), B, L, x.shape[1], eps, _stream(x))
+
+
 def rmsnorm_gate_residual_bwd(h, inv_rms, ssg, dy, dh, dssg, B, L):
     C = h.shape[1]
     _f32(ssg, inv_rms, dssg)

@@ -9,7 +9,7 @@ OBJS=""
 for s in gemm rowops misc heads optim attn style latent; do
   o=build/$s.o
   if [ ! -f "$o" ] || [ "$CS/$s.hip" -nt "$o" ] || [ "$CS/od_common.h" -nt "$o" ] || [ "$CS/od_tiles.h" -nt "$o" ] || [ emu_hip.h -nt "$o" ]; then
-    /opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fPIC -DOD_EMU -DOD_GEMM_BIG_MIN_M=256 -I. -I$CS -Wno-unused-value -c $CS/$s.hip -o $o &
+    /opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fPIC -DOD_EMU -DOD_GEMM_BIG_MIN_M=256 -DOD_DW_SMALL_THREADS=10 -DOD_GEMM_SMALL_TILES=6 -I. -I$CS -Wno-unused-value -c $CS/$s.hip -o $o &
   fi
   OBJS="$OBJS $o"
 done

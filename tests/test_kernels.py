@@ -238,6 +238,29 @@ def test_qk_norm_rope(dev, dtype, H, hd):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,with_cl", [(64, True), (512, False), (1024, True)])
+def test_rmsnorm_gate_residual_film_equals_pair(dev, dtype, C, with_cl):
+    """The fused forward kernel against the two kernels it replaces: identical bits (xo is rounded before the
+    second norm), broadcast and per-sample cl."""
+    g = torch.Generator().manual_seed(21)
+    B, L = 2, 19
+    M = B * L
+    x, h = mk((M, C), g, dev, dtype), mk((M, C), g, dev, dtype)
+    ssg_a, ssg_b = mk((B, 3 * C), g, dev, scale=0.3), mk((B, 3 * C), g, dev, scale=0.3)
+    for bcast in (False, True):
+        cl = mk((L if bcast else M, C), g, dev, dtype) if with_cl else None
+        xo_ref, h2_ref = torch.zeros_like(x), torch.zeros_like(x)
+        inv_a_ref, inv_b_ref = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+        ops.rmsnorm_gate_residual(x, h, ssg_a, xo_ref, inv_a_ref, B, L)
+        ops.rmsnorm_film(xo_ref, ssg_b, cl, bcast, h2_ref, inv_b_ref, B, L)
+        xo, h2 = torch.zeros_like(x), torch.zeros_like(x)
+        inv_a, inv_b = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+        ops.rmsnorm_gate_residual_film(x, h, ssg_a, xo, inv_a, ssg_b, cl, bcast, h2, inv_b, B, L)
+        assert torch.equal(xo, xo_ref) and torch.equal(h2, h2_ref)
+        assert torch.equal(inv_a, inv_a_ref) and torch.equal(inv_b, inv_b_ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,L,hd", [(1, 2, 150, 32), (2, 1, 64, 64), (1, 1, 257, 64), (1, 1, 5, 32)])
 def test_flash_attention(dev, dtype, B, H, L, hd):
     g = torch.Generator().manual_seed(8)
@@ -270,9 +293,10 @@ def test_flash_attention(dev, dtype, B, H, L, hd):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ks", [3, 5])
-def test_dwconv(dev, dtype, ks):
+@pytest.mark.parametrize("L", [75, 21])          # long-run and short-run launch shapes (od_dwconv picks by size)
+def test_dwconv(dev, dtype, ks, L):
     g = torch.Generator().manual_seed(9)
-    B, L, C = 2, 75, 24
+    B, C = 2, 24
     x = mk((B * L, C), g, dev, dtype)
     w, b = mk((C, 1, ks), g, dev, scale=.4), mk((C,), g, dev)
     y = torch.zeros_like(x)
