@@ -133,13 +133,24 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
         for (int s = 0; s < NS; s++) od_frag_load(fq[qi][s], qb + (size_t)row * ldq + s * 32 + g * 8);
     }
     f32x4 oacc[2][ND];
-    float mrun[2], lrun[2];      // running max of the RAW scores, running sum
+    // Softmax against a LAZY reference (VALU diet: the loop is bound by the vector ALU, not the MFMA — 32 exps at
+    // quarter rate per lane per tile already cost as many cycles as the 32 MFMAs).  mref[qi] is a per-query
+    // reference score, set to the row max of the first key tile and raised only when a later tile exceeds it by
+    // more than 2^OD_FWD_SLACK; the score accumulators START at -mref (the MFMA's C operand), so p = 2^(c * acc)
+    // takes one packed multiply per pair — no fma, no cross-lane max, no rescale of O on the common path.
+    // p <= 2^OD_FWD_SLACK keeps fp32 sums and bf16 P far from overflow; the result is the same softmax
+    // (shift invariance), lse = mref * scale + ln(l).
+    float mref[2], lrun[2];
 #pragma unroll
     for (int qi = 0; qi < 2; qi++) {
-        mrun[qi] = NEG_BIG; lrun[qi] = 0.f;
+        mref[qi] = 0.f; lrun[qi] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < ND; dt++) oacc[qi][dt] = (f32x4)(0.f);
     }
+#ifndef OD_FWD_SLACK
+#define OD_FWD_SLACK 8.0f
+#endif
+    const float inv_c = 1.0f / c;
 
     const int nkt = (L + 63) / 64;
     St sk, sv;
@@ -155,8 +166,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
     if constexpr (St::TR) dma(0, smem);
     else { sk.load(kb, ldk, 0, L); sv.load(vb, ldv, 0, L); lstore(smem); }
     __syncthreads();
-    auto tile = [&](int kt, auto masked_t) {
+    auto tile = [&](int kt, auto masked_t, auto first_t) {
         constexpr bool MASKED = decltype(masked_t)::value;
+        constexpr bool FIRST = decltype(first_t)::value;
         const unsigned char* tK = smem + (kt & 1) * 2 * St::BYTES;
         const unsigned char* tV = tK + St::BYTES;
         if (kt + 1 < nkt) {
@@ -164,8 +176,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
             else { sk.load(kb, ldk, (kt + 1) * 64, L); sv.load(vb, ldv, (kt + 1) * 64, L); }
         }
 
-        // S^T tiles: rows = keys (4 tiles of 16), cols = queries
-        f32x4 sacc[2][4];
+        // S^T tiles: rows = keys (4 tiles of 16), cols = queries; accumulators start at -mref
+        f32x4 e[2][4];
 #pragma unroll
         for (int t4 = 0; t4 < 4; t4++) {
             od_frag<T> fk[NS];
@@ -173,10 +185,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
             for (int s = 0; s < NS; s++) frag_contig<St::ROWB>(fk[s], tK, t4 * 16 + x, s * 32 + g * 8);
 #pragma unroll
             for (int qi = 0; qi < 2; qi++) {
-                f32x4 a = (f32x4)(0.f);
+                f32x4 a = (f32x4)(-mref[qi]);
 #pragma unroll
                 for (int s = 0; s < NS; s++) a = od_mma(fk[s], fq[qi][s], a);
-                sacc[qi][t4] = a;
+                e[qi][t4] = a * c;                       // log2 units relative to the reference
             }
         }
         const int kbase = kt * 64;
@@ -187,33 +199,49 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
                 for (int t4 = 0; t4 < 4; t4++)
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        if (kbase + t4 * 16 + 4 * g + r >= L) sacc[qi][t4][r] = NEG_BIG;
+                        if (kbase + t4 * 16 + 4 * g + r >= L) e[qi][t4][r] = NEG_BIG;
         }
-        // online softmax; lane owns query column x, keys 16*t4 + 4g + r.  p = 2^(c*s - c*m)
+        // lane-local maxima (lane owns query column x, keys 16*t4 + 4g + r)
+        float mx[2];
+#pragma unroll
+        for (int qi = 0; qi < 2; qi++) {
+            mx[qi] = fmaxf(fmaxf(e[qi][0][0], e[qi][0][1]), fmaxf(e[qi][0][2], e[qi][0][3]));
+#pragma unroll
+            for (int t4 = 1; t4 < 4; t4++)
+                mx[qi] = fmaxf(mx[qi], fmaxf(fmaxf(e[qi][t4][0], e[qi][t4][1]), fmaxf(e[qi][t4][2], e[qi][t4][3])));
+        }
+        // rare path (always on the first tile): move the reference.  Wave-uniform branch.
+        if (FIRST || __any(fmaxf(mx[0], mx[1]) > OD_FWD_SLACK)) {
+#pragma unroll
+            for (int qi = 0; qi < 2; qi++) {
+                float m = mx[qi];
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const float d = FIRST ? m : fmaxf(m, 0.f);
+                if constexpr (!FIRST) {
+                    const float alpha = od_exp2(-d);
+                    lrun[qi] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < ND; dt++) oacc[qi][dt] *= alpha;
+                }
+                mref[qi] += d * inv_c;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++) e[qi][t4] -= d;
+            }
+        }
         od_frag<T> fp[2][2];
 #pragma unroll
         for (int qi = 0; qi < 2; qi++) {
-            float mx = fmaxf(fmaxf(sacc[qi][0][0], sacc[qi][0][1]), fmaxf(sacc[qi][0][2], sacc[qi][0][3]));
-#pragma unroll
-            for (int t4 = 1; t4 < 4; t4++)
-                mx = fmaxf(mx, fmaxf(fmaxf(sacc[qi][t4][0], sacc[qi][t4][1]), fmaxf(sacc[qi][t4][2], sacc[qi][t4][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qi], mx);
-            const float alpha = od_exp2((mrun[qi] - mnew) * c);
-            mrun[qi] = mnew;
-            const float mc = -mnew * c;
-            float ps = 0.f;
+            f32x4 ps = (f32x4)(0.f);
 #pragma unroll
             for (int t4 = 0; t4 < 4; t4++) {
-                const float p0 = od_exp2(fmaf(sacc[qi][t4][0], c, mc)), p1 = od_exp2(fmaf(sacc[qi][t4][1], c, mc));
-                const float p2 = od_exp2(fmaf(sacc[qi][t4][2], c, mc)), p3 = od_exp2(fmaf(sacc[qi][t4][3], c, mc));
-                ps += (p0 + p1) + (p2 + p3);
-                od_frag_set4(fp[qi][t4 >> 1], t4 & 1, p0, p1, p2, p3);
-            }
-            lrun[qi] = lrun[qi] * alpha + ps;
+                f32x4 p;
 #pragma unroll
-            for (int dt = 0; dt < ND; dt++) oacc[qi][dt] *= alpha;
+                for (int r = 0; r < 4; r++) p[r] = od_exp2(e[qi][t4][r]);
+                ps += p;
+                od_frag_set4(fp[qi][t4 >> 1], t4 & 1, p[0], p[1], p[2], p[3]);
+            }
+            lrun[qi] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         }
         // O^T += V^T P^T
 #pragma unroll
@@ -229,8 +257,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
         __syncthreads();
     };
     const int nfull = L / 64;
-    for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
-    if (nfull < nkt) tile(nfull, std::true_type{});
+    if (nfull > 0) tile(0, std::false_type{}, std::true_type{});
+    else tile(0, std::true_type{}, std::true_type{});
+    for (int kt = 1; kt < nfull; kt++) tile(kt, std::false_type{}, std::false_type{});
+    if (nfull > 0 && nfull < nkt) tile(nfull, std::true_type{}, std::false_type{});
 #pragma unroll
     for (int qi = 0; qi < 2; qi++) {
         float l = lrun[qi];
@@ -243,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
 #pragma unroll
             for (int dt = 0; dt < ND; dt++)
                 st4(orow + dt * 16 + 4 * g, oacc[qi][dt][0] * inv, oacc[qi][dt][1] * inv, oacc[qi][dt][2] * inv, oacc[qi][dt][3] * inv);
-            if (g == 0) lse[((size_t)b * H + h) * L + row] = (mrun[qi] * c + log2f(l)) * LN2;
+            if (g == 0) lse[((size_t)b * H + h) * L + row] = (mref[qi] * c + log2f(l)) * LN2;
         }
     }
 }
@@ -299,7 +329,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
     const float* lseb = lse + ((size_t)b * H + h) * L;
     const float* delb = delta + ((size_t)b * H + h) * L;
     const int key0 = ktile * KB + wave * NK * 16;
-    const float c = scale * LOG2E;
+    // VALU diet: the score and dP accumulators START at -lse/scale and -delta (the MFMA's C operand), so
+    // P = exp2(c * acc) and dS' = P * acc' need one packed multiply each — no fma/sub per element; the factor
+    // `scale` of dS is applied once to dK at the end.
+    const float c = scale * LOG2E, inv_scale = 1.0f / scale;
 
     od_frag<T> fk[NK][NS], fv[NK][NS];
 #pragma unroll
@@ -333,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
         sq.store_rowmajor(st); so.store_rowmajor(st + St::BYTES);
         if constexpr (!St::TR) { sq.store_transposed(st + 2 * St::BYTES); so.store_transposed(st + 3 * St::BYTES); }
         float* sl = (float*)(st + (2 + 2 * St::NT) * St::BYTES);
-        if (threadIdx.x < 64) { sl[threadIdx.x] = r_lse * LOG2E; sl[64 + threadIdx.x] = r_del; }
+        if (threadIdx.x < 64) { sl[threadIdx.x] = -r_lse * inv_scale; sl[64 + threadIdx.x] = -r_del; }
     };
     // bf16: Q/dO tiles by LDS-DMA into the other stage at the top of the iteration; lse/delta by registers
     auto gload_small = [&](int qt) {
@@ -345,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
     };
     auto lstore_small = [&](unsigned char* st) {
         float* sl = (float*)(st + (2 + 2 * St::NT) * St::BYTES);
-        if (threadIdx.x < 64) { sl[threadIdx.x] = r_lse * LOG2E; sl[64 + threadIdx.x] = r_del; }
+        if (threadIdx.x < 64) { sl[threadIdx.x] = -r_lse * inv_scale; sl[64 + threadIdx.x] = -r_del; }
     };
     auto dma = [&](int qt, unsigned char* st) {
         St::dma_rowmajor(qb, ldq, qt * 64, L, st);
@@ -384,21 +417,22 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
             const f32x4 d4 = *(const f32x4*)(s_delta + t4 * 16 + 4 * g);
 #pragma unroll
             for (int ki = 0; ki < NK; ki++) {
-                f32x4 sa = (f32x4)(0.f), pa = (f32x4)(0.f);
+                f32x4 sa = l4, pa = d4;
 #pragma unroll
                 for (int s = 0; s < NS; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
-                float p[4];
+                const f32x4 e = sa * c;
+                f32x4 p;
 #pragma unroll
-                for (int r = 0; r < 4; r++) p[r] = od_exp2(fmaf(sa[r], c, -l4[r]));
+                for (int r = 0; r < 4; r++) p[r] = od_exp2(e[r]);
                 if constexpr (MASKED) {
                     const bool kvalid = key0 + ki * 16 + x < L;
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         if (!(kvalid && (qbase + t4 * 16 + 4 * g + r < L))) p[r] = 0.f;
                 }
+                const f32x4 ds = p * pa;
                 od_frag_set4(fp[ki][t4 >> 1], t4 & 1, p[0], p[1], p[2], p[3]);
-                od_frag_set4(fds[ki][t4 >> 1], t4 & 1, p[0] * (pa[0] - d4[0]) * scale, p[1] * (pa[1] - d4[1]) * scale,
-                             p[2] * (pa[2] - d4[2]) * scale, p[3] * (pa[3] - d4[3]) * scale);
+                od_frag_set4(fds[ki][t4 >> 1], t4 & 1, ds[0], ds[1], ds[2], ds[3]);
             }
         }
         // dV^T += dO^T P ; dK^T += Q^T dS     (A rows = features, k = permuted queries, cols = keys)
@@ -434,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
             T* dvr = dv + ((size_t)b * L + row) * lddv + h * HD;
 #pragma unroll
             for (int dt = 0; dt < ND; dt++) {
+                dkacc[ki][dt] *= scale;
                 st4(dkr + dt * 16 + 4 * g, dkacc[ki][dt][0], dkacc[ki][dt][1], dkacc[ki][dt][2], dkacc[ki][dt][3]);
                 st4(dvr + dt * 16 + 4 * g, dvacc[ki][dt][0], dvacc[ki][dt][1], dvacc[ki][dt][2], dvacc[ki][dt][3]);
             }
@@ -463,7 +498,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
     const T* vb = v + (size_t)b * L * ldv + h * HD;
     const T* dob = dout + (size_t)b * L * lddo + h * HD;
     const int q0 = qtile * QB + wave * NQ * 16;
-    const float c = scale * LOG2E;
+    const float c = scale * LOG2E, inv_scale = 1.0f / scale;     // accumulator-init trick, see the dK/dV kernel
 
     od_frag<T> fq[NQ][NS], fdo[NQ][NS];
     float r_lse[NQ], r_del[NQ];
@@ -475,8 +510,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
             od_frag_load(fq[qi][s], qb + (size_t)row * ldq + s * 32 + g * 8);
             od_frag_load(fdo[qi][s], dob + (size_t)row * lddo + s * 32 + g * 8);
         }
-        r_lse[qi] = lse[((size_t)b * H + h) * L + row] * LOG2E;
-        r_del[qi] = delta[((size_t)b * H + h) * L + row];
+        r_lse[qi] = -lse[((size_t)b * H + h) * L + row] * inv_scale;
+        r_del[qi] = -delta[((size_t)b * H + h) * L + row];
     }
     f32x4 dqacc[NQ][ND];
 #pragma unroll
@@ -520,19 +555,20 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
             }
 #pragma unroll
             for (int qi = 0; qi < NQ; qi++) {
-                f32x4 sa = (f32x4)(0.f), pa = (f32x4)(0.f);
+                f32x4 sa = (f32x4)(r_lse[qi]), pa = (f32x4)(r_del[qi]);
 #pragma unroll
                 for (int s = 0; s < NS; s++) { sa = od_mma(fkr[s], fq[qi][s], sa); pa = od_mma(fvr[s], fdo[qi][s], pa); }
-                float p[4];
+                const f32x4 e = sa * c;
+                f32x4 p;
 #pragma unroll
-                for (int r = 0; r < 4; r++) p[r] = od_exp2(fmaf(sa[r], c, -r_lse[qi]));
+                for (int r = 0; r < 4; r++) p[r] = od_exp2(e[r]);
                 if constexpr (MASKED) {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         if (kbase + t4 * 16 + 4 * g + r >= L) p[r] = 0.f;
                 }
-                od_frag_set4(fds[qi][t4 >> 1], t4 & 1, p[0] * (pa[0] - r_del[qi]) * scale, p[1] * (pa[1] - r_del[qi]) * scale,
-                             p[2] * (pa[2] - r_del[qi]) * scale, p[3] * (pa[3] - r_del[qi]) * scale);
+                const f32x4 ds = p * pa;
+                od_frag_set4(fds[qi][t4 >> 1], t4 & 1, ds[0], ds[1], ds[2], ds[3]);
             }
         }
 #pragma unroll
@@ -558,8 +594,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
         if (row < L) {
             T* dqr = dq + ((size_t)b * L + row) * lddq + h * HD;
 #pragma unroll
-            for (int dt = 0; dt < ND; dt++)
+            for (int dt = 0; dt < ND; dt++) {
+                dqacc[qi][dt] *= scale;
                 st4(dqr + dt * 16 + 4 * g, dqacc[qi][dt][0], dqacc[qi][dt][1], dqacc[qi][dt][2], dqacc[qi][dt][3]);
+            }
         }
     }
 }

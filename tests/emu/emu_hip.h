@@ -158,6 +158,18 @@ inline T shfl(T v, int src) {
 
 inline void __syncthreads() { emu::block_barrier(); }
 template <class T> inline T __shfl_xor(T v, int m, int width = 64) { (void)width; return emu::shfl(v, emu::lane_id() ^ m); }
+// wave vote: true in every lane if the predicate holds in any lane
+inline int __any(int pred) {
+    emu::State& s = emu::S();
+    int w = emu::wave_id(), l = emu::lane_id();
+    int v = pred != 0;
+    memcpy(s.xbuf[w][l], &v, sizeof(int));
+    emu::wave_barrier();
+    int r = 0;
+    for (int i = 0; i < 64; i++) { int t; memcpy(&t, s.xbuf[w][i], sizeof(int)); r |= t; }
+    emu::wave_barrier();
+    return r;
+}
 template <class T> inline T __shfl(T v, int src, int width = 64) { (void)width; return emu::shfl(v, src); }
 template <class T> inline T __shfl_down(T v, int d, int width = 64) { (void)width; int l = emu::lane_id(); return emu::shfl(v, (l + d) < 64 ? l + d : l); }
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }

@@ -55,6 +55,35 @@ def test_gemm_nt_f32x3(dev, M, N, K):
     assert rel_l2(C, O.silu(ref)) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("L,hd", [(300, 64), (257, 32)])
+def test_flash_attention_reference_moves(dev, dtype, L, hd):
+    """Scores whose row maximum keeps growing along the key axis (and spans ~100 nats): the forward's lazy
+    softmax reference has to move on later key tiles, not only on the first one."""
+    g = torch.Generator().manual_seed(13)
+    B, H = 1, 2
+    M, dh = B * L, H * hd
+    q = (torch.randn(M, dh, generator=g) * 3).to(dtype)
+    k = (torch.randn(M, dh, generator=g) * (0.2 + 4.0 * torch.arange(L)[:, None] / L)).to(dtype)
+    v = torch.randn(M, dh, generator=g).to(dtype)
+    scale = 1 / math.sqrt(hd)
+
+    def heads(t):
+        return t.double().reshape(B, L, H, hd).permute(0, 2, 1, 3)
+    s = heads(q) @ heads(k).transpose(-1, -2) * scale
+    first, later = s[..., :64].amax(-1), s[..., 64:].amax(-1)
+    assert float((later - first).max()) > 30, "the fixture must push the maximum up after the first tile"
+    ref = (torch.softmax(s, -1) @ heads(v)).permute(0, 2, 1, 3).reshape(M, dh).float()
+    o = torch.zeros(M, dh, dtype=dtype, device=dev)
+    lse = torch.zeros(B, H, L, device=dev)
+    ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), o, lse, B, H, L, hd, scale)
+    assert rel_l2(o.float(), ref) < TOL[dtype]
+    assert rel_l2(lse, torch.logsumexp(s, -1).float()) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+    if dtype == torch.float32:
+        ops.flash_attn_fwd(q.to(dev), k.to(dev), v.to(dev), o, lse, B, H, L, hd, scale, x3=True)
+        assert rel_l2(o, ref) < 5e-5
+
+
 @pytest.mark.parametrize("B,H,L,hd", [(1, 2, 150, 32), (1, 1, 257, 64), (2, 1, 64, 64)])
 def test_flash_attention_fwd_f32x3(dev, B, H, L, hd):
     g = torch.Generator().manual_seed(12)
