@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
             }
             const f32x4 l4 = *(const f32x4*)(s_lse + t4 * 16 + 4 * g);
             const f32x4 d4 = *(const f32x4*)(s_delta + t4 * 16 + 4 * g);
+
 #pragma unroll
             for (int ki = 0; ki < NK; ki++) {
                 f32x4 sa = l4, pa = d4;
