@@ -55,13 +55,18 @@ __global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ 
     }
 }
 
+// dW[c][e] += sum_m dx[m][c] xt[b][e][l], db[c] += sum_m dx[m][c].  A wave walks frames with 8 channels per lane
+// (D <= 512 per pass); the four waves of a block are summed in LDS and each block issues ONE atomic per output
+// element (all blocks hit the same D*(E+1) addresses, so the atomic count per address is what costs).
 template <class T>
 __global__ __launch_bounds__(256) void proj_in_bwd_kernel(const float* __restrict__ xt, const T* __restrict__ dx, int ldx,
                                                           float* __restrict__ dW, float* __restrict__ db, int B, int E, int L, int D) {
-    const int lane = threadIdx.x & 63;
-    const long M = (long)B * L;
-    const long nw = (long)gridDim.x * 4, w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (int c = lane * 8; c < D; c += 512) {
+    __shared__ float red[64][73];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int M = B * L;
+    const int nw = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+    for (int c0 = 0; c0 < D; c0 += 512) {
+        const int c = c0 + lane * 8;
         float aw[8][8], ab[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -69,26 +74,41 @@ __global__ __launch_bounds__(256) void proj_in_bwd_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 8; e++) aw[k][e] = 0.f;
         }
-        for (long m = w0; m < M; m += nw) {
-            const int b = (int)(m / L), l = (int)(m % L);
-            float xe[8], g[8];
+        if (c < D)
+            for (int m = w0; m < M; m += nw) {
+                const int b = m / L, l = m - b * L;
+                float xe[8], g[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) xe[e] = e < E ? xt[((size_t)b * E + e) * L + l] : 0.f;
-            od_ld8(dx + m * ldx + c, g);
+                for (int e = 0; e < 8; e++) xe[e] = e < E ? xt[((size_t)b * E + e) * L + l] : 0.f;
+                od_ld8(dx + (size_t)m * ldx + c, g);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    ab[k] += g[k];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) aw[k][e] += g[k] * xe[e];
+                }
+            }
+        for (int w = 0; w < 4; w++) {
+            if (wave == w) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    red[lane][k * 9 + 8] = (w ? red[lane][k * 9 + 8] : 0.f) + ab[k];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) red[lane][k * 9 + e] = (w ? red[lane][k * 9 + e] : 0.f) + aw[k][e];
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0 && c < D) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                ab[k] += g[k];
+                atomicAdd(db + c + k, red[lane][k * 9 + 8]);
 #pragma unroll
-                for (int e = 0; e < 8; e++) aw[k][e] += g[k] * xe[e];
+                for (int e = 0; e < 8; e++)
+                    if (e < E) atomicAdd(dW + (size_t)(c + k) * E + e, red[lane][k * 9 + e]);
             }
         }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            atomicAdd(db + c + k, ab[k]);
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-                if (e < E) atomicAdd(dW + (size_t)(c + k) * E + e, aw[k][e]);
-        }
+        __syncthreads();
     }
 }
 
@@ -308,8 +328,17 @@ __global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __res
     const int kl = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kl;
     float s = 0.f;
-    if (k < K)
-        for (int n = slice; n < N; n += 4) s += dpre[(size_t)b * N + n] * W[(size_t)n * K + k];
+    if (k < K) {
+        // 8 independent loads in flight per lane (the loop is latency-bound otherwise: N/4 dependent iterations)
+        float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int n = slice;
+        for (; n + 28 < N; n += 32) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) s8[j] += dpre[(size_t)b * N + n + 4 * j] * W[(size_t)(n + 4 * j) * K + k];
+        }
+        for (; n < N; n += 4) s8[0] += dpre[(size_t)b * N + n] * W[(size_t)n * K + k];
+        s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
     red[slice][kl] = s;
     __syncthreads();
     if (slice == 0 && k < K) {
@@ -365,7 +394,8 @@ extern "C" int od_proj_in_bwd(int dtype, const float* xt, const void* dx, int ld
     if (E > 8) return OD_ERR_UNSUPPORTED;
     if (D % 8 || ldx % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
-    int blocks = (int)((M + 63) / 64); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    if (M > 0x7fffffffL) return OD_ERR_UNSUPPORTED;
+    int blocks = (int)((M + 63) / 64); if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
     DISPATCH_T(dtype, OD_LAUNCH((proj_in_bwd_kernel<T_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, xt, (const T_*)dx, ldx, dW, db, B, E, L, D));
     OD_CHECK_LAUNCH();
     return 0;
