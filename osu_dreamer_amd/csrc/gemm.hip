@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
                                                       int M, int N, int K, int accumulate) {
     constexpr int BK = 128 / (int)sizeof(T);  // elements per slab row
     constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+    constexpr int ASZ = 32 * WMT * 128;                    // A tile bytes per stage (BMT rows x 128 B)
+    constexpr int STG = ASZ + 16384;                       // + W tile: 48 KiB of LDS at WMT = 2, 64 at 4
+    constexpr int CSZ = 32 * WMT * 512;                    // epilogue image, f32 [BMT][128]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG > CSZ ? 2 * STG : CSZ];
 
     constexpr int BMT = 32 * WMT;
     const int tiles_m = (M + BMT - 1) / BMT, tiles_n = (N + BN - 1) / BN;
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         }
     };
     auto lstore = [&](int buf) {
-        unsigned char* sA = smem + buf * STAGE_BYTES;
-        unsigned char* sB = sA + 16384;
+        unsigned char* sA = smem + buf * STG;
+        unsigned char* sB = sA + ASZ;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         // LDS-DMA staging (requires K % BK == 0): wave w streams 1 KiB pieces = 8 tile rows x 128 B; the
         // XOR swizzle is applied to the SOURCE column so the LDS image is the same one the reads expect.
         auto dma = [&](int kt, int buf) {
-            unsigned char* sA = smem + buf * STAGE_BYTES;
-            unsigned char* sB = sA + 16384;
+            unsigned char* sA = smem + buf * STG;
+            unsigned char* sB = sA + ASZ;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int row = (wave * 4 + i) * 8 + (lane >> 3);
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
         for (int kt = 0; kt < nk; kt++) {
             const int buf = kt & 1;
             if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
-            compute_stage<T, WMT>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+            compute_stage<T, WMT>(smem + buf * STG, smem + buf * STG + ASZ, wm, wn, lane, acc);
             __syncthreads();
         }
     } else {
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        compute_stage<T, WMT>(smem + buf * STAGE_BYTES, smem + buf * STAGE_BYTES + 16384, wm, wn, lane, acc);
+        compute_stage<T, WMT>(smem + buf * STG, smem + buf * STG + ASZ, wm, wn, lane, acc);
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
