@@ -42,6 +42,13 @@ const char* od_error_string(int code);
  *           model.py:45 (proj_audio), and their autograd backward-data. */
 int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                int M, int N, int K, int epilogue, int accumulate, void* stream);
+/* the qkv projection with the q/k RMSNorm + RoPE applied in its epilogue (no-grad forward / sampler: no separate
+ * od_qk_norm_rope pass): C[:, :2*H*hd] = rope(rms_norm(A W^T + bias) * w), C[:, 2*H*hd:] = A W^T + bias.
+ * hd in {32, 64}; the pre-norm values are rounded to dtype first, so the result equals od_gemm_nt + od_qk_norm_rope.
+ * replaces: attn.py:74-80. */
+int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
+                      int N, int K, const float* wq, const float* wk, const float* table, int L, int H, int hd, float eps,
+                      void* stream);
 /* dW[N,K] (fp32, ld lddw) += G[M,N]^T A[M,K]; if dbias != NULL also dbias[N] += column sums of G
  * — autograd weight and bias gradients of the above, G read once. */
 int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M, int N,

@@ -77,12 +77,20 @@ __device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int& tm,
     return tm < tiles_m;
 }
 
+// OD_EPI_QKROPE (internal): the q/k RMSNorm + RoPE of attn.py:74-80 applied to the first n_rope columns of the output
+// tile while it sits in LDS (a 128-column tile holds whole heads), the remaining columns (v) stored as they are.
+struct RopeEpi {
+    const float* wq; const float* wk; const float* table;   // norm weights [hd], (cos, sin) table [L][hd/2][2]
+    int L, dh, hd, n_rope; float eps;                        // dh = H*hd (q columns), n_rope = 2*dh
+};
+constexpr int OD_EPI_QKROPE = 2;
+
 // WMT = 16-row MFMA tiles per wave along m: 4 -> 128 x 128 block tile, 2 -> 64 x 128 (twice the workgroups, for
 // launches whose 128-row tiling would leave CUs idle: the sampler's M = B*L = 4460 against N = 512)
 template <class T, int EPI, bool DMA, int WMT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                       const float* __restrict__ bias, T* __restrict__ C, int ldc,
-                                                      int M, int N, int K, int accumulate) {
+                                                      int M, int N, int K, int accumulate, RopeEpi rp) {
     constexpr int BK = 128 / (int)sizeof(T);  // elements per slab row
     constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
     constexpr int ASZ = 32 * WMT * 128;                    // A tile bytes per stage (BMT rows x 128 B)
@@ -188,6 +196,49 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
     }
     __syncthreads();
     const bool vec_ok = (N % 8 == 0) && (ldc % 8 == 0);
+    if constexpr (EPI == OD_EPI_QKROPE) {
+        // (launcher guarantees N % 8 == 0, ldc % 8 == 0, n_rope % 128 == 0, hd in {32, 64}, bias != null)
+        const int half = rp.hd >> 1, lph = rp.hd >> 3;          // lanes (8-column chunks) per head
+#pragma unroll
+        for (int i = 0; i < 2 * WMT; i++) {
+            const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+            const int gm = m0 + row, gn = n0 + ch * 8;
+            const bool valid = gm < M && gn < N;
+            const bool roped = n0 < rp.n_rope;                  // block-uniform
+            float v[8], bv[8];
+            od_ld8(sC + row * 128 + ch * 8, v);
+            od_ld8(bias + (gn < N ? gn : 0), bv);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = od_round_to<T>(v[e] + bv[e]);   // what the unfused path reads back from qkv
+            if (roped) {
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) ss += v[e] * v[e];
+                for (int msk = 1; msk < lph; msk <<= 1) ss += __shfl_xor(ss, msk);
+                const float inv = rsqrtf(ss / (float)rp.hd + rp.eps);
+                const int pc = ch ^ (lph >> 1);                 // chunk holding the rotary partners (d +- hd/2)
+                float pv[8], pb[8];
+                od_ld8(sC + row * 128 + pc * 8, pv);
+                od_ld8(bias + (gn < N ? n0 + pc * 8 : 0), pb);
+                const int d0 = (ch * 8) & (rp.hd - 1), dp = (pc * 8) & (rp.hd - 1);
+                const float* w = gn < rp.dh ? rp.wq : rp.wk;
+                float wv[8], wp[8], t0[8], t1[8];                 // weights of own / partner chunk, 8 (cos, sin) pairs
+                od_ld8(w + d0, wv); od_ld8(w + dp, wp);
+                const float* tb = rp.table + ((size_t)((gm < M ? gm : 0) % rp.L) * half + (d0 & (half - 1))) * 2;
+                od_ld8(tb, t0); od_ld8(tb + 8, t1);
+                const bool lo = d0 < half;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float y = v[e] * inv * wv[e];
+                    const float yp = od_round_to<T>(pv[e] + pb[e]) * inv * wp[e];
+                    const float cs = e < 4 ? t0[2 * e] : t1[2 * e - 8], sn = e < 4 ? t0[2 * e + 1] : t1[2 * e - 7];
+                    v[e] = lo ? y * cs - yp * sn : yp * sn + y * cs;
+                }
+            }
+            if (valid) od_st8(C + (size_t)gm * ldc + gn, v);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2 * WMT; i++) {
         const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
@@ -614,16 +665,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ G, in
 
 template <class T>
 int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C, int ldc, int M, int N, int K, int epi,
-              int accumulate, hipStream_t st) {
+              int accumulate, hipStream_t st, RopeEpi rp = RopeEpi{}) {
     const int tiles_n = (N + BN - 1) / BN;
 #ifndef OD_GEMM_SMALL_TILES
 #define OD_GEMM_SMALL_TILES 512     // fewer 128-row tiles than 2 per CU: use 64-row tiles (the emulator build lowers it)
 #endif
     const bool half = ((M + 127) / 128) * tiles_n < OD_GEMM_SMALL_TILES;
-    const int tiles_m = half ? (M + 63) / 64 : (M + 127) / 128;
+#ifndef OD_GEMM_QUARTER_TILES
+#define OD_GEMM_QUARTER_TILES 0
+#endif
+    const bool quarter = ((M + 63) / 64) * tiles_n < OD_GEMM_QUARTER_TILES;
+    const int tiles_m = quarter ? (M + 31) / 32 : half ? (M + 63) / 64 : (M + 127) / 128;
     const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const bool dma = (K % (128 / (int)sizeof(T))) == 0;
-    if (dma && M >= OD_GEMM_BIG_MIN_M && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
+    if (epi != OD_EPI_QKROPE && dma && M >= OD_GEMM_BIG_MIN_M && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
         const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256;
         const int grid2 = ((tm2 + 7) / 8) * 8 * tn2;
         if (epi == OD_EPI_SILU)
@@ -633,9 +688,11 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
         OD_CHECK_LAUNCH();
         return 0;
     }
-#define NT_GO(EPI_, DMA_, WMT_) OD_LAUNCH((gemm_nt_kernel<T, EPI_, DMA_, WMT_>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate)
-#define NT_GO2(EPI_, DMA_) do { if (half) NT_GO(EPI_, DMA_, 2); else NT_GO(EPI_, DMA_, 4); } while (0)
-    if (epi == OD_EPI_SILU) {
+#define NT_GO(EPI_, DMA_, WMT_) OD_LAUNCH((gemm_nt_kernel<T, EPI_, DMA_, WMT_>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, rp)
+#define NT_GO2(EPI_, DMA_) do { if (quarter) NT_GO(EPI_, DMA_, 1); else if (half) NT_GO(EPI_, DMA_, 2); else NT_GO(EPI_, DMA_, 4); } while (0)
+    if (epi == OD_EPI_QKROPE) {
+        if (dma) NT_GO2(OD_EPI_QKROPE, true); else NT_GO2(OD_EPI_QKROPE, false);
+    } else if (epi == OD_EPI_SILU) {
         if (dma) NT_GO2(OD_EPI_SILU, true); else NT_GO2(OD_EPI_SILU, false);
     } else {
         if (dma) NT_GO2(OD_EPI_NONE, true); else NT_GO2(OD_EPI_NONE, false);
@@ -689,6 +746,24 @@ extern "C" int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int 
         return launch_nt<float>((const float*)A, lda, (const float*)W, ldw, bias, (float*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
     if (dtype == OD_F32X3)
         return launch_nt<f32x3_t>((const f32x3_t*)A, lda, (const f32x3_t*)W, ldw, bias, (f32x3_t*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
+    return OD_ERR_ARG;
+}
+
+extern "C" int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                                 int M, int N, int K, const float* wq, const float* wk, const float* table, int L, int H, int hd,
+                                 float eps, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !bias || !wq || !wk || !table || L <= 0) return OD_ERR_ARG;
+    const int ch = dtype == OD_BF16 ? 8 : 4;
+    if (lda % ch || ldw % ch || K % ch || N % 8 || ldc % 8) return OD_ERR_ALIGN;
+    const int n_rope = 2 * H * hd;
+    if ((hd != 32 && hd != 64) || n_rope % 128 || n_rope > N) return OD_ERR_UNSUPPORTED;
+    const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps};
+    if (dtype == OD_BF16)
+        return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
+    if (dtype == OD_F32)
+        return launch_nt<float>((const float*)A, lda, (const float*)W, ldw, bias, (float*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
+    if (dtype == OD_F32X3)
+        return launch_nt<f32x3_t>((const f32x3_t*)A, lda, (const f32x3_t*)W, ldw, bias, (f32x3_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
     return OD_ERR_ARG;
 }
 

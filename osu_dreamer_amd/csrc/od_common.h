@@ -83,6 +83,7 @@ template <> struct od_t<bf16_t> {
 template <class T> __device__ __forceinline__ float od_round_to(float x);
 template <> __device__ __forceinline__ float od_round_to<float>(float x) { return x; }
 template <> __device__ __forceinline__ float od_round_to<bf16_t>(float x) { return od_bf2f(od_f2bf(x)); }
+template <> __device__ __forceinline__ float od_round_to<f32x3_t>(float x) { return x; }
 
 // 8 consecutive elements <-> 8 floats (p must be 16-byte aligned for bf16, 32 for f32)
 __device__ __forceinline__ void od_ld8(const float* p, float (&v)[8]) {

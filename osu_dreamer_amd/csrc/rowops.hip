@@ -861,7 +861,7 @@ extern "C" int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const floa
     if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
     if (ldqkv % 8 || ldo % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
-    if (OD_QK_HEAD && (hd == 64 || hd == 32) && 64 % (2 * H) == 0) {       // lane-per-head kernel
+    if (OD_QK_HEAD && (hd == 64 || hd == 32) && 64 % (2 * H) == 0 && H >= 2) {       // lane-per-head kernel (its LDS table holds 64 frames per block: 4 * 64/(2H) <= 64)
         const int rpw = 64 / (2 * H);
         dim3 g2((unsigned)((M + 4 * rpw - 1) / (4 * rpw)));
 #define QKH(TT, HDV) OD_LAUNCH((qk_norm_rope_head_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (TT*)qk_out, ldo, M, L, H, eps)

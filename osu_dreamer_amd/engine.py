@@ -193,10 +193,16 @@ class DenoiserEngine:
             # --- attention branch (backbone.py:76-80, attn.py:74-84); h1 = norm + FiLM + proj_cl(a) came from the
             #     kernel that closed the previous layer
             qkv = self.lbuf("qkv", i, (M, 3 * dh))
-            ops.gemm_nt(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv, x3=self.x3)
-            qk = self.lbuf("qk", i, (M, 2 * dh))
-            ops.qk_norm_rope(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, qk,
-                             B, L, self.H, self.hd, FP32_EPS)
+            if self.train or self.hd not in (32, 64) or (2 * dh) % 128:
+                ops.gemm_nt(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv, x3=self.x3)
+                qk = self.lbuf("qk", i, (M, 2 * dh))         # backward needs the pre-norm q, k as well
+                ops.qk_norm_rope(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, qk,
+                                 B, L, self.H, self.hd, FP32_EPS)
+            else:                                             # no-grad: norm + RoPE in the GEMM's epilogue, in place
+                ops.gemm_nt_qkrope(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv,
+                                   self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, L,
+                                   self.H, self.hd, FP32_EPS, x3=self.x3)
+                qk = qkv
             y = self.lbuf("y", i, (M, dh))
             lse = self.lbuf("lse", i, (B, self.H, L), f32)
             ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, self.H, L, self.hd,

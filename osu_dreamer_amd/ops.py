@@ -56,6 +56,16 @@ def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False, x3=False):
                           epilogue, int(accumulate), _stream(A))
 
 
+def gemm_nt_qkrope(A, W, bias, C, wq, wk, table, L, H, hd, eps, x3=False):
+    """qkv projection with q/k RMSNorm + RoPE in the epilogue (forward-only): C[:, :2*H*hd] normed + rotated."""
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and tuple(C.shape) == (M, N) and A.dtype == W.dtype == C.dtype
+    _f32(bias, wq, wk, table)
+    _lib.lib().od_gemm_nt_qkrope(mm_code(A.dtype, x3), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
+                                 _p(wq), _p(wk), _p(table), L, H, hd, eps, _stream(A))
+
+
 def gemm_tn(G, A, dW, n_cols=None, k_cols=None, dbias=None):
     """dW[N,K] += G[:, :N]^T A[:, :K] (and dbias[N] += column sums of G);  dW is any fp32 tensor
     viewed as [N, K] rows."""

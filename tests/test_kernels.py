@@ -38,6 +38,31 @@ def test_gemm_nt(dev, dtype, M, N, K):
     assert rel_l2(C.float(), ref - b.cpu() + C0.float().cpu()) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,hd,L,B,K", [(2, 64, 70, 2, 64), (4, 32, 33, 3, 96), (1, 64, 300, 1, 40)])
+def test_gemm_nt_qkrope_equals_gemm_then_rope(dev, dtype, H, hd, L, B, K):
+    """The fused epilogue against od_gemm_nt followed by od_qk_norm_rope (same rounding point; only the order of
+    the 64-term sum of squares differs)."""
+    g = torch.Generator().manual_seed(31)
+    M, dh = B * L, H * hd
+    A, W, b = mk((M, K), g, dev, dtype), mk((3 * dh, K), g, dev, dtype, 0.3), mk((3 * dh,), g, dev)
+    wq, wk = 1 + 0.2 * mk((hd,), g, dev), 1 + 0.2 * mk((hd,), g, dev)
+    tab = torch.zeros(L, hd // 2, 2, device=dev)
+    ops.rope_table(tab, L, hd)
+    eps = 1.2e-7
+    qkv = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
+    ops.gemm_nt(A, W, b, qkv)
+    qk = torch.zeros(M, 2 * dh, dtype=dtype, device=dev)
+    ops.qk_norm_rope(qkv, wq, wk, tab, qk, B, L, H, hd, eps)
+    fused = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
+    ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps)
+    assert torch.equal(fused[:, 2 * dh:], qkv[:, 2 * dh:])                      # v columns untouched
+    assert rel_l2(fused[:, :2 * dh].float(), qk.float()) < (2e-6 if dtype == torch.float32 else 3e-3)
+    if dtype == torch.float32:
+        ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps, x3=True)
+        assert rel_l2(fused[:, :2 * dh], qk) < 2e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(200, 136, 96), (300, 384, 192), (512, 512, 256)])
 def test_gemm_nt_f32x3(dev, M, N, K):
     """OD_F32X3: fp32 tensors, three bf16 MFMAs per product.  Tolerance 2e-5 rel-L2 against fp64
