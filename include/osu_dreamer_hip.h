@@ -226,10 +226,15 @@ int od_unet_down(int dtype, const void* x, int ldx, const float* w, const float*
 /* nearest Upsample(stride) then the same depthwise Conv1d: x [B*Li][C] -> y [B*Li*stride][C].  replaces: unet.py:80-85. */
 int od_unet_up(int dtype, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int Li, int C,
                int stride, void* stream);
-/* out (B,N,L) fp32 = f_n(bias[n] + W[n] . x[(b,l)]), f_n = sigmoid for n < n_sigmoid else identity (N <= 16).
- * replaces: latent/model.py:114 (proj_out) + :127-131 (hit-signal sigmoid). */
+/* out (B,N,L) fp32 = f_n(bias[n] + W[n] . x[(b,l)]), f_n = sigmoid for n < n_sigmoid else identity (N <= 16); with
+ * rms != 0 the N outputs of each frame are RMS-normalised (no gain).
+ * replaces: latent/model.py:114 (proj_out) + :127-131 (hit-signal sigmoid); :65-68 (temporal_head). */
 int od_chart_head(int dtype, const void* x, int ldx, const float* W, const float* bias, float* out, int B, int L, int C, int N,
-                  int n_sigmoid, void* stream);
+                  int n_sigmoid, int rms, float eps, void* stream);
+/* out[b][h*hd + d] (fp32) = sum_l softmax_l(scores[(b,l)][h]) * values[(b,l)][h*hd + d]   (hd <= 256).
+ * replaces: AttnPool.forward, latent/model.py:33-36 (the two 1x1 convs before it are od_gemm_nt). */
+int od_attn_pool(int dtype, const void* scores, int lds, const void* values, int ldv, float* out, int B, int L, int Hh, int hd,
+                 void* stream);
 
 /* ---- hipGraph helpers for the captured sampler loop ---------------------------------- */
 int od_graph_begin(void* stream);

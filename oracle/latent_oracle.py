@@ -5,6 +5,8 @@ Functional torch restatement of the two steps either side of `diffusion.sample` 
 
   * `LatentModel.audio_encoder`  = SpecFeatures (models/latent/spec_features.py:10-32) + UNetEncoder
     (models/latent/unet.py:55-75)                                         -> (skips, h)
+  * `LatentModel.encode_chart`   = chart_encoder -> style_head (layer, AttnPool, rms_norm) -> temporal layer / head
+    (models/latent/model.py:23-36,93-101) — the dataset-encoding direction (scripts/encode_latents.py)
   * `LatentModel.decode`         = proj_emb -> UNetDecoder (unet.py:77-101, mixer :117-126, layer :21-53)
     -> proj_out -> sigmoid on the hit signals, label_predictor clamp       (models/latent/model.py:103-134)
 
@@ -120,6 +122,45 @@ def init_latent_params(d: LatentDims, seed: int) -> Dict[str, torch.Tensor]:
     return P
 
 
+def latent_encoder_param_shapes(d: LatentDims, style_head_dim: int, style_heads: int) -> Dict[str, tuple]:
+    """The rest of `LatentModel.state_dict()`: what `encode_chart` reads (chart_encoder, style_head, temporal_*)."""
+    D, ks = d.h_dim, 1 + 2 * (d.stride // 2)
+    s = {"chart_encoder.0.weight": (D, X_DIM, 1), "chart_encoder.0.bias": (D,)}
+    for i in range(d.n_downs):
+        s[f"chart_encoder.1.downs.{i}.0.weight"] = (D, 1, ks); s[f"chart_encoder.1.downs.{i}.0.bias"] = (D,)
+    for i in range(d.n_downs):
+        s.update(_layer_shapes(f"chart_encoder.1.layers.{i}.", d, cond=False))
+    s.update(_layer_shapes("style_head.0.", d, cond=False))
+    hd = style_head_dim * style_heads
+    s["style_head.1.scores.weight"] = (style_heads, D, 1); s["style_head.1.scores.bias"] = (style_heads,)
+    s["style_head.1.values.weight"] = (hd, D, 1); s["style_head.1.values.bias"] = (hd,)
+    s["style_head.1.proj_out.weight"] = (d.style_dim, hd); s["style_head.1.proj_out.bias"] = (d.style_dim,)
+    s.update(_layer_shapes("temporal_layer.", d, cond=True))
+    s["temporal_head.0.weight"] = (d.emb_dim, D, 1); s["temporal_head.0.bias"] = (d.emb_dim,)
+    return s
+
+
+def init_latent_encoder_params(d: LatentDims, seed: int, style_head_dim: int, style_heads: int) -> Dict[str, torch.Tensor]:
+    """Seeded values for the encode_chart parameters (own generator: init_latent_params' stream is untouched)."""
+    g = torch.Generator().manual_seed(seed + 50)
+    P = {}
+    for name, shape in latent_encoder_param_shapes(d, style_head_dim, style_heads).items():
+        if name.endswith("gamma"):
+            base = 0.3 if ".blocks." in name else 1.0
+            t = base * (1.0 + 0.2 * torch.randn(shape, generator=g))
+        elif name.endswith("bias"):
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif ".films." in name:
+            t = 0.3 * torch.randn(shape, generator=g) / math.sqrt(shape[1])
+        else:
+            fan_in = 1
+            for n in shape[1:]:
+                fan_in *= n
+            t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        P[name] = t
+    return P
+
+
 # ---------------------------------------------------------------------------------------------------
 def rms_norm(x, gamma=None):                      # common/rms_norm.py:6-16 (dim 1, eps 1e-6)
     y = x * x.pow(2).mean(dim=1, keepdim=True).add(1e-6).rsqrt()
@@ -200,6 +241,20 @@ def decode(P, z, s, skips, d: LatentDims):                                      
     logits = decode_logits(P, z, s, skips, d)
     chart = torch.cat([logits[:, :N_HIT].sigmoid(), logits[:, N_HIT:]], dim=1)
     return chart, label_predictor(P, s).clamp(0, 10)
+
+
+def attn_pool(P, p, x, heads: int):                                                     # latent/model.py:23-36
+    a = F.conv1d(x, P[p + "scores.weight"], P[p + "scores.bias"]).softmax(dim=-1)       # B H L
+    v = F.conv1d(x, P[p + "values.weight"], P[p + "values.bias"]).unflatten(1, (heads, -1))   # B H D L
+    return F.linear(torch.einsum("bhl,bhdl->bhd", a, v).flatten(1), P[p + "proj_out.weight"], P[p + "proj_out.bias"])
+
+
+def encode_chart(P, chart, d: LatentDims, style_heads: int):                            # latent/model.py:93-101
+    x = F.conv1d(chart, P["chart_encoder.0.weight"], P["chart_encoder.0.bias"])
+    _, h = unet_encoder(P, "chart_encoder.1.", x, d)
+    s = rms_norm(attn_pool(P, "style_head.1.", layer(P, "style_head.0.", h, None, d), style_heads))
+    z = rms_norm(F.conv1d(layer(P, "temporal_layer.", h, s, d), P["temporal_head.0.weight"], P["temporal_head.0.bias"]))
+    return z, s
 
 
 def pad_to_multiple(x, chunk):                                                          # data/modules/beatmap.py:26-30

@@ -310,16 +310,17 @@ def gen_latent(out_dir, name, d, B, Ba, L, seed):
     from osu_dreamer.models.latent.model import LatentModel, LatentModelArgs
     from osu_dreamer.models.latent.unet import LayerArgs
     P = LO.init_latent_params(d, seed)
+    PE = LO.init_latent_encoder_params(d, seed, 8, 2)
     m = LatentModel(d.emb_dim, d.style_dim, d.n_downs, d.stride,
                     LatentModelArgs(h_dim=d.h_dim, ae_args=LayerArgs(n_layers=d.n_layers, expand=d.expand, radius=d.radius),
                                     style_head_dim=8, style_heads=2))
     sd = m.state_dict()
-    for k, w in P.items():
+    for k, w in {**P, **PE}.items():
         assert k in sd and tuple(sd[k].shape) == tuple(w.shape), k
     on_path = ("audio_encoder.", "proj_emb.", "decoder.", "proj_out.", "label_predictor.")
     assert sorted(k for k in sd if k.startswith(on_path)) == sorted(P.keys())
-    res = m.load_state_dict(P, strict=False)
-    assert not res.unexpected_keys and all(not k.startswith(on_path) for k in res.missing_keys)
+    assert sorted(sd.keys()) == sorted({**P, **PE}.keys())       # the two oracle inventories are the whole state dict
+    m.load_state_dict({**P, **PE})
     m.eval()
     assert L % d.chunk_size == 0
     g = torch.Generator().manual_seed(seed + 1)
@@ -334,21 +335,26 @@ def gen_latent(out_dir, name, d, B, Ba, L, seed):
         chart, labels = m.decode(z, s, skips=list(skips))
         chart2, _ = m.decode(z, s, audio=audio)
         assert torch.equal(chart, chart2)
+        # the dataset-encoding direction on a synthetic chart (hit signals in [0,1], cursor in [-1,1])
+        chart_in = torch.cat([torch.rand(B, 7, L, generator=g), torch.rand(B, 2, L, generator=g) * 2 - 1], dim=1)
+        enc_z, enc_s = m.encode_chart(chart_in)
+        o_z, o_s = LO.encode_chart({**P, **PE}, chart_in, d, 2)
         # the restatement against the reference, on the spot
         o_skips, o_h = LO.audio_encoder(P, audio, d)
         o_chart, o_labels = LO.decode(P, z, s, o_skips, d)
     def rel(a, b):
         return float((a - b).norm() / b.norm())
     assert rel(o_h, h) < 2e-6 and rel(o_chart, chart) < 2e-6 and rel(o_labels, labels) < 2e-6, (rel(o_h, h), rel(o_chart, chart))
-    fx = {"dims": np.array([d.emb_dim, d.style_dim, d.n_downs, d.stride, d.h_dim, d.n_layers, d.expand, d.radius]),
+    assert rel(o_z, enc_z) < 2e-6 and rel(o_s, enc_s) < 2e-6, (rel(o_z, enc_z), rel(o_s, enc_s))
+    fx = {"chart_in": chart_in, "enc_z": enc_z, "enc_s": enc_s,"dims": np.array([d.emb_dim, d.style_dim, d.n_downs, d.stride, d.h_dim, d.n_layers, d.expand, d.radius]),
           "seed": seed, "audio": audio, "z": z, "s": s, "feat": feat, "h": h, "chart": chart, "labels": labels}
     for i, sk in enumerate(skips):
         fx[f"skip{i}"] = sk
     if d.h_dim <= 64:
-        for k, w in P.items():
+        for k, w in {**P, **PE}.items():
             fx["w." + k] = w
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
-    print(name, "oracle-vs-reference", rel(o_h, h), rel(o_chart, chart))
+    print(name, "oracle-vs-reference", rel(o_h, h), rel(o_chart, chart), rel(o_z, enc_z), rel(o_s, enc_s))
 
 
 def gen_ldm(out_dir, name, ld, sd_, dd, B, L, num_steps, seed):

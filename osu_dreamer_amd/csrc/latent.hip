@@ -147,27 +147,66 @@ __global__ __launch_bounds__(256) void unet_up_kernel(const T* __restrict__ x, i
     od_st8(y + m * ldy + c, o);
 }
 
-// out[b][n][l] = f_n( bias[n] + sum_c W[n][c] x[(b,l)][c] ),  f_n = sigmoid for n < n_sigmoid, identity after
-// — proj_out + the hit-signal sigmoid of decode                      latent/model.py:114,127-131
+// out[b][n][l] = f_n( bias[n] + sum_c W[n][c] x[(b,l)][c] ),  f_n = sigmoid for n < n_sigmoid, identity after;
+// with rms != 0 the N outputs of a frame are RMS-normalised (no gain) instead
+// — proj_out + the hit-signal sigmoid of decode (latent/model.py:114,127-131); temporal_head (:65-68)
 template <class T, int NMAX>
 __global__ __launch_bounds__(256) void chart_head_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ out, long M, int L,
-                                                         int C, int N, int n_sigmoid) {
+                                                         int C, int N, int n_sigmoid, int rms, float eps) {
     OD_ROW_OF_LANE();
     float v[8];
     od_ld8(x + mr * ldx + c, v);
     const int b = (int)(mr / L), l = (int)(mr % L);
+    float y[NMAX], ss = 0.f;
 #pragma unroll
     for (int n = 0; n < NMAX; n++) {
-        if (n >= N) break;
+        y[n] = 0.f;
+        if (n >= N) continue;
         float wv[8], s = 0.f;
         od_ld8(W + (size_t)n * C + c, wv);
 #pragma unroll
         for (int e = 0; e < 8; e++) s += wv[e] * v[e];
         s = group_sum(s, G) + bias[n];
         if (n < n_sigmoid) s = od_sigmoid(s);
-        if (live && c == 0) out[((size_t)b * N + n) * L + l] = s;
+        y[n] = s; ss += s * s;
     }
+    const float k = rms ? rsqrtf(ss / (float)N + eps) : 1.f;
+#pragma unroll
+    for (int n = 0; n < NMAX; n++)
+        if (n < N && live && c == 0) out[((size_t)b * N + n) * L + l] = y[n] * k;
+}
+
+// AttnPool (latent/model.py:23-36): out[b][h*hd + d] = sum_l softmax_l(scores[(b,l)][h]) * values[(b,l)][h*hd + d].
+// One block per (b, h); thread = feature d (hd <= 256), softmax statistics by a block reduction over the frames.
+template <class T>
+__global__ __launch_bounds__(256) void attn_pool_kernel(const T* __restrict__ scores, int lds_, const T* __restrict__ values, int ldv,
+                                                        float* __restrict__ out, int L, int Hh, int hd) {
+    __shared__ float red[256];
+    __shared__ float s_p[256];
+    const int b = blockIdx.y, h = blockIdx.x, t = threadIdx.x;
+    const T* sb = scores + (size_t)b * L * lds_ + h;
+    float mx = -3.0e38f;
+    for (int l = t; l < L; l += 256) mx = fmaxf(mx, od_t<T>::ld(sb + (size_t)l * lds_));
+    red[t] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] = fmaxf(red[t], red[t + s]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float acc = 0.f, den = 0.f;
+    for (int l0 = 0; l0 < L; l0 += 256) {
+        const int l = l0 + t;
+        s_p[t] = l < L ? __expf(od_t<T>::ld(sb + (size_t)l * lds_) - mx) : 0.f;
+        __syncthreads();
+        const int n = L - l0 < 256 ? L - l0 : 256;
+        if (t < hd) {
+            const T* vb = values + ((size_t)b * L + l0) * ldv + h * hd + t;
+            for (int j = 0; j < n; j++) acc += s_p[j] * od_t<T>::ld(vb + (size_t)j * ldv);
+        }
+        for (int j = 0; j < n; j++) den += s_p[j];       // every thread keeps the same denominator
+        __syncthreads();
+    }
+    if (t < hd) out[(size_t)b * Hh * hd + h * hd + t] = acc / den;
 }
 
 // ---- SpecFeatures front end (spec_features.py:17-26): two strided Conv2d over (freq, time), each followed by a
@@ -321,12 +360,21 @@ extern "C" int od_unet_up(int dtype, const void* x, int ldx, const float* w, con
 }
 
 extern "C" int od_chart_head(int dtype, const void* x, int ldx, const float* W, const float* bias, float* out, int B, int L, int C,
-                             int N, int n_sigmoid, void* stream) {
+                             int N, int n_sigmoid, int rms, float eps, void* stream) {
     if (!lanes_ok(C) || ldx % 8) return OD_ERR_ALIGN;
     if (N < 1 || N > 16) return OD_ERR_UNSUPPORTED;
     const long M = (long)B * L;
     DISPATCH_T(dtype, OD_LAUNCH((chart_head_kernel<T_, 16>), dim3(row_grid(M, C)), dim3(256), 0, (hipStream_t)stream, (const T_*)x,
-                                ldx, W, bias, out, M, L, C, N, n_sigmoid));
+                                ldx, W, bias, out, M, L, C, N, n_sigmoid, rms, eps));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_attn_pool(int dtype, const void* scores, int lds, const void* values, int ldv, float* out, int B, int L, int Hh,
+                            int hd, void* stream) {
+    if (hd < 1 || hd > 256 || Hh < 1 || L < 1) return OD_ERR_UNSUPPORTED;
+    DISPATCH_T(dtype, OD_LAUNCH((attn_pool_kernel<T_>), dim3(Hh, B), dim3(256), 0, (hipStream_t)stream, (const T_*)scores, lds,
+                                (const T_*)values, ldv, out, L, Hh, hd));
     OD_CHECK_LAUNCH();
     return 0;
 }

@@ -7,11 +7,12 @@ reference checkpoint / inference artifact loads with `strict=True`), and the cal
 
     skips, h = model.audio_encoder(audio)           # (Ba,72,L) -> [ (Ba,h_dim,L/stride^i) ], (Ba,h_dim,L/stride^n)
     chart, labels = model.decode(z, s, skips=skips) # or audio=...;   also decode_logits(z, s, ...)
+    z, s = model.encode_chart(chart)                # (B,9,L) -> (B,emb_dim,L/chunk), (B,style_dim)
 
 Activations are frame-major [B*L][h_dim] on the device; the tensors handed back are (B, C, L)-shaped *views* of
-those buffers (no transposing copy), and `decode` takes them back without one.  `encode_chart` (chart encoder,
-style head, temporal head — the training / dataset-encoding side) is not on this path: its parameters are
-carried for checkpoint compatibility and calling it raises.  Parameters do not receive gradients here.
+those buffers (no transposing copy), and `decode` takes them back without one.  `encode_chart(chart) -> (z, s)`
+(chart encoder, style head, temporal head: the dataset-encoding direction of scripts/encode_latents.py) runs on
+the same kernels.  Training of the latent model is out of scope: parameters do not receive gradients here.
 """
 from __future__ import annotations
 
@@ -199,7 +200,9 @@ class LatentModel(nn.Module):
 
     def _layer_prefixes(self) -> List[Tuple[str, bool]]:
         out = [(f"audio_encoder.1.layers.{i}.", False) for i in range(self.n_downs)]
-        return out + [(f"decoder.layers.{i}.", True) for i in range(self.n_downs)]
+        out += [(f"decoder.layers.{i}.", True) for i in range(self.n_downs)]
+        out += [(f"chart_encoder.1.layers.{i}.", False) for i in range(self.n_downs)]
+        return out + [("style_head.0.", False), ("temporal_layer.", True)]
 
     def _pack(self, dt: torch.dtype):
         """fp32 parameters -> GEMM operands of the compute dtype; SwiGLU width padded hf -> hp (zero rows/cols)."""
@@ -224,6 +227,9 @@ class LatentModel(nn.Module):
                 ops.pack_weight(self.P(name + ".bias"), pk[name + ".b"].view(Np, 1), row_map=rmap)
 
         pack("audio_encoder.0.net.8")
+        pack("chart_encoder.0", Kp=16)                      # 9 chart channels, zero-padded to one 16-wide k chunk
+        pack("style_head.1.scores")
+        pack("style_head.1.values")
         for p, _ in self._layer_prefixes():
             for i in range(self.args.ae_args.n_layers):
                 pack(f"{p}blocks.{i}.0.proj_vg.1", Np=2 * hp, rmap=rowmap)
@@ -378,6 +384,51 @@ class LatentModel(nn.Module):
     def forward(self, audio, z, s):                                          # latent/model.py:78-91
         return self.decode_logits(z, s, audio=audio), self._label_predictor(s.detach().to(torch.float32).contiguous())
 
-    def encode_chart(self, chart):
-        raise NotImplementedError("encode_chart (chart encoder / style head / temporal head) is the training and "
-                                  "dataset-encoding side of the latent model; only audio_encoder and decode are compiled")
+    # ------------------------------------------------------------------ latent/model.py:93-101 (encode_chart)
+    @torch.no_grad()
+    def encode_chart(self, chart: torch.Tensor):
+        """chart (B, 9, L) -> z (B, emb_dim, L / chunk_size), s (B, style_dim): the dataset-encoding direction
+        (scripts/encode_latents.py): chart encoder, style head (layer + AttnPool + rms_norm), temporal layer / head."""
+        chart = chart.detach().to(torch.float32).contiguous()
+        B, X, L = chart.shape
+        if X != X_DIM:
+            raise ValueError(f"chart must have {X_DIM} signals, got {X}")
+        if L % self.chunk_size:
+            raise ValueError(f"chart length {L} is not a multiple of chunk_size {self.chunk_size} (pad_to_multiple first)")
+        dt, D, x3 = self._dtype(), self.a_dim, self._x3()
+        self._pack(dt)
+        ws = self._workspace("chart", B, L, dt)
+        cf = ws.get("cf", (B * L, 16), dt)                   # columns 9..15 stay zero
+        ops.cl_to_frames(chart, cf)
+        x = ws.get("x0", (B * L, D), dt)
+        ops.gemm_nt(cf, self._packed["chart_encoder.0"], self.P("chart_encoder.0.bias"), x, x3=x3)
+        Li = L
+        for i in range(self.n_downs):
+            y = self._layer(ws, f"l{i}", f"chart_encoder.1.layers.{i}.", x, None, B, Li)
+            Lo = Li // self.stride
+            x = ws.get(f"x{i + 1}", (B * Lo, D), dt)
+            ops.unet_down(y, self.P(f"chart_encoder.1.downs.{i}.0.weight"), self.P(f"chart_encoder.1.downs.{i}.0.bias"),
+                          x, B, Lo, self.stride)
+            Li = Lo
+        h = x                                                 # [B*l][D]; both heads below read it
+        # style head: layer -> AttnPool -> rms_norm (no gain)
+        hs = ws.get("hs", (B * Li, D), dt)
+        hs.copy_(h)                                           # _layer updates its input in place
+        y = self._layer(ws, "sh", "style_head.0.", hs, None, B, Li)
+        heads, hd = self.args.style_heads, self.args.style_head_dim
+        sc = ws.get("sc", (B * Li, heads), dt)
+        va = ws.get("va", (B * Li, heads * hd), dt)
+        ops.gemm_nt(y, self._packed["style_head.1.scores"], self.P("style_head.1.scores.bias"), sc, x3=x3)
+        ops.gemm_nt(y, self._packed["style_head.1.values"], self.P("style_head.1.values.bias"), va, x3=x3)
+        pooled = ws.get("pooled", (B, heads * hd), torch.float32)
+        ops.attn_pool(sc, va, pooled, B, Li, heads, hd)
+        s_pre = ws.get("s_pre", (B, self.style_dim), torch.float32)
+        ops.linear_small(pooled, self.P("style_head.1.proj_out.weight"), self.P("style_head.1.proj_out.bias"), s_pre)
+        s = torch.empty(B, self.style_dim, dtype=torch.float32, device=chart.device)
+        ops.rmsnorm_rows(s_pre, None, s, 1e-6)
+        # temporal layer (FiLM from s) -> Conv1d(D -> emb_dim) -> rms_norm over the emb_dim channels
+        y = self._layer(ws, "tl", "temporal_layer.", h, s, B, Li)
+        z = torch.empty(B, self.emb_dim, Li, dtype=torch.float32, device=chart.device)
+        ops.chart_head(y, self.P("temporal_head.0.weight").view(self.emb_dim, D), self.P("temporal_head.0.bias"), z, B, Li, 0,
+                       rms=True)
+        return z, s

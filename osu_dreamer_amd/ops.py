@@ -381,8 +381,14 @@ def unet_up(x, w, bias, y, B, Li, stride):
                           _stream(x))
 
 
-def chart_head(x, W, bias, out, B, L, n_sigmoid):
+def chart_head(x, W, bias, out, B, L, n_sigmoid, rms=False, eps=1e-6):
     _f32(W, bias, out)
     N = W.shape[0]
     _lib.lib().od_chart_head(dt_code(x.dtype), _p(x), _ld(x), _p(W), _p(bias), _p(out), B, L, x.shape[1], N, n_sigmoid,
-                             _stream(x))
+                             int(rms), eps, _stream(x))
+
+
+def attn_pool(scores, values, out, B, L, heads, hd):
+    _f32(out)
+    _lib.lib().od_attn_pool(dt_code(scores.dtype), _p(scores), _ld(scores), _p(values), _ld(values), _p(out), B, L, heads, hd,
+                            _stream(scores))
