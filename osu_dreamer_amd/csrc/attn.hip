@@ -306,14 +306,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 // dK, dV: block owns 4 waves x NK*16 keys; loop over 64-query tiles.
 //   S = Q K^T (cols = keys) ; dV^T += dO^T P ; dP = dO V^T ; dS = P*(dP - delta)*scale ; dK^T += Q^T dS
 // LDS per stage: Q, dO row-major (+ Q^T, dO^T for f32); bf16 double-buffers the stage.
-template <class T, int HD, int NK>
-__global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+template <class T, int HD, int NK, int NWK>
+__global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                                const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                T* __restrict__ dk, int lddk, T* __restrict__ dv, int lddv,
                                                                int B, int H, int L, float scale) {
     using St = Stage<T, HD>;
-    constexpr int NS = HD / 32, ND = HD / 16, KB = 4 * NK * 16;
+    constexpr int NS = HD / 32, ND = HD / 16, KB = NWK * NK * 16;
+    static_assert(NWK == 4 || St::TR, "the register-staged (f32) path assumes 256 threads");
     constexpr int NSTAGE = St::TR ? 2 : 1;
     constexpr int STAGE = (2 + 2 * St::NT) * St::BYTES + 512;     // tiles + (lse, delta)
     OD_DYN_SMEM(smem);
@@ -381,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv_kernel(const T* __restri
         if (threadIdx.x < 64) { sl[threadIdx.x] = -r_lse * inv_scale; sl[64 + threadIdx.x] = -r_del; }
     };
     auto dma = [&](int qt, unsigned char* st) {
-        St::dma_rowmajor(qb, ldq, qt * 64, L, st);
-        St::dma_rowmajor(dob, lddo, qt * 64, L, st + St::BYTES);
+        St::template dma_rowmajor<NWK>(qb, ldq, qt * 64, L, st);
+        St::template dma_rowmajor<NWK>(dob, lddo, qt * 64, L, st + St::BYTES);
     };
     if constexpr (St::TR) { dma(0, smem); gload_small(0); lstore_small(smem); }
     else { gload(0); lstore(smem); }
@@ -624,8 +625,12 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     const long M = (long)B * L;
     OD_LAUNCH((attn_delta_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)o, ldo, (const T*)dout, lddo, delta,
               B, H, L, HD);
-    const int gk = attn_grid((L + 64 * NK - 1) / (64 * NK), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK>), dim3(gk), dim3(256), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+#ifndef OD_DKV_NW
+#define OD_DKV_NW 4      // waves per dK/dV workgroup (bf16): 8 = the Q/dO tiles streamed once per 256 keys
+#endif
+    constexpr int NWK = Stage<T, HD>::TR ? OD_DKV_NW : 4;
+    const int gk = attn_grid((L + 16 * NWK * NK - 1) / (16 * NWK * NK), B * H);
+    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK, NWK>), dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale);
     constexpr int NWQ = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
     const int gq = attn_grid((L + 16 * NQ * NWQ - 1) / (16 * NQ * NWQ), B * H);
