@@ -37,8 +37,25 @@ struct dim3 {
 };
 
 namespace emu {
+#if defined(__x86_64__)
+#define EMU_FAST_SWITCH 1
+// Minimal SysV x86-64 context switch (callee-saved registers + stack pointer).  glibc's swapcontext makes two
+// rt_sigprocmask system calls per switch, which dominated the emulator's run time.
+__attribute__((naked, noinline)) static void emu_switch(void** /*save_sp*/, void* /*load_sp*/) {
+    asm volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq %rsi, %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+        "ret");
+}
+#else
+#define EMU_FAST_SWITCH 0
+#endif
+
 struct Fiber {
     ucontext_t ctx;
+    void* sp = nullptr;
     char* stack = nullptr;
     bool done = false;
     dim3 tid;
@@ -46,6 +63,7 @@ struct Fiber {
 struct State {
     dim3 threadIdx, blockIdx, blockDim, gridDim;
     ucontext_t sched;
+    void* sched_sp = nullptr;
     std::vector<Fiber> fibers;
     int cur = -1;
     int nthreads = 0;
@@ -63,7 +81,11 @@ inline State& S() { static State s; return s; }
 inline void yield() {
     State& s = S();
     Fiber& f = s.fibers[s.cur];
+#if EMU_FAST_SWITCH
+    emu_switch(&f.sp, s.sched_sp);
+#else
     swapcontext(&f.ctx, &s.sched);
+#endif
 }
 inline int lane_id() { State& s = S(); return s.cur & 63; }
 inline int wave_id() { State& s = S(); return s.cur >> 6; }
@@ -93,7 +115,12 @@ inline void trampoline() {
     s.body();
     s.fibers[s.cur].done = true;
     on_exit_thread();
+#if EMU_FAST_SWITCH
+    emu_switch(&s.fibers[s.cur].sp, s.sched_sp);
+    __builtin_trap();                 // a finished fiber is never resumed
+#else
     swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+#endif
 }
 
 template <class F>
@@ -119,11 +146,21 @@ void launch(dim3 grid, dim3 block, F&& f) {
             fb.done = false;
             fb.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             s.wave_alive[t >> 6]++;
+#if EMU_FAST_SWITCH
+            // initial frame: six callee-saved slots, then the entry point as emu_switch's return address; the stack is
+            // 16-byte aligned + 8 at trampoline's first instruction, as after a call
+            void** top = (void**)(((uintptr_t)fb.stack + STK) & ~(uintptr_t)15);
+            *--top = nullptr;                            // fake return address of trampoline (never used)
+            *--top = (void*)trampoline;                  // emu_switch's `ret` lands here
+            for (int r = 0; r < 6; r++) *--top = nullptr;
+            fb.sp = top;
+#else
             getcontext(&fb.ctx);
             fb.ctx.uc_stack.ss_sp = fb.stack;
             fb.ctx.uc_stack.ss_size = STK;
             fb.ctx.uc_link = nullptr;
             makecontext(&fb.ctx, (void (*)())trampoline, 0);
+#endif
         }
         int remaining = nt;
         while (remaining > 0) {
@@ -131,7 +168,11 @@ void launch(dim3 grid, dim3 block, F&& f) {
                 Fiber& fb = s.fibers[t];
                 if (fb.done) continue;
                 s.cur = t; s.threadIdx = fb.tid;
+#if EMU_FAST_SWITCH
+                emu_switch(&s.sched_sp, fb.sp);
+#else
                 swapcontext(&s.sched, &fb.ctx);
+#endif
                 if (fb.done) remaining--;
             }
         }

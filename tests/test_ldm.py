@@ -74,12 +74,11 @@ def test_ldm_sample_vs_reference(dev, name):
     assert float(chart[:, :7].min()) >= 0 and float(chart[:, :7].max()) <= 1
     assert float(out_labels.min()) >= 0 and float(out_labels.max()) <= 10
     # faster product mode stays inside the same bound; unpinned noise draws fresh samples of the right shape
-    if dev.type == "cuda":         # (the emulator runs the pinned sample above; these repeats are GPU-only to keep the CPU suite short)
-        m.set_precision(None, "bf16x3")
-        c3, _ = m.sample(audio, labels, n, s_init=fx["s_init"].to(dev), x_init=fx["x_init"].to(dev))
-        assert rel_l2(c3, fx["chart"]) < 1e-4
-        m.set_precision()
-    c4, l4 = m.sample(audio, labels, n if dev.type == "cuda" else 1)
+    m.set_precision(None, "bf16x3")
+    c3, _ = m.sample(audio, labels, n, s_init=fx["s_init"].to(dev), x_init=fx["x_init"].to(dev))
+    assert rel_l2(c3, fx["chart"]) < 1e-4
+    m.set_precision()
+    c4, l4 = m.sample(audio, labels, n)
     assert tuple(c4.shape) == tuple(chart.shape) and torch.isfinite(c4).all() and not torch.equal(c4, chart)
     with pytest.raises(ValueError):
         m.sample(audio[None], labels, n)
@@ -113,7 +112,6 @@ def test_inference_artifact_roundtrip(dev, tmp_path):
     assert not m.training
     for k, v in m.state_dict().items():
         assert torch.equal(v.cpu(), full[k]), k
-    if dev.type == "cuda":
-        chart, _ = m.sample(fx["audio"].to(dev), fx["labels"].to(dev), int(fx["num_steps"]), s_init=fx["s_init"].to(dev),
-                            x_init=fx["x_init"].to(dev))
-        assert rel_l2(chart, fx["chart"]) < 1e-4
+    chart, _ = m.sample(fx["audio"].to(dev), fx["labels"].to(dev), int(fx["num_steps"]), s_init=fx["s_init"].to(dev),
+                        x_init=fx["x_init"].to(dev))
+    assert rel_l2(chart, fx["chart"]) < 1e-4

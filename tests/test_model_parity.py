@@ -99,8 +99,7 @@ def run_case(name, dev):
     model.f32_matmul = "bf16x3"
     with torch.no_grad():
         u3, v3 = model(dd["h"], dd["s"], xt)
-    # (the x3 sampler repeat is GPU-only: the emulator already ran the fp32 sampler above)
-    xs3 = model.sample(dd["h"], dd["s"], int(fx["num_steps"]), x_init=dd["x_init"]) if dev.type == "cuda" else xs
+    xs3 = model.sample(dd["h"], dd["s"], int(fx["num_steps"]), x_init=dd["x_init"])
     model.f32_matmul = "f32"
     assert not torch.equal(v3, v), "f32_matmul='bf16x3' must reach the f32x3 kernels"
     assert rel_l2(v3, fx["fwd_v"]) < 5e-5 and rel_l2(u3, fx["fwd_u"]) < 1e-5
