@@ -328,7 +328,7 @@ def main():
         executed = f_fwd + 2 * (f_fwd - attn_fwd) + 3.5 * attn_fwd
         line = {
             "metric": "denoiser train-steps/sec + 50-step sample latents/sec, 1/2/4/8 MI355X",
-            "value": round(world * args.steps / dt, 4), "unit": "train-steps/s (rank-steps of batch 32 x 8192 frames)",
+            "value": round(world * args.steps / dt, 4), "unit": f"train-steps/s (rank-steps of batch {B} x {L} frames)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
