@@ -1,3 +1,5 @@
+"""Attention backward alone (od_flash_attn_bwd = delta + dK/dV + dQ kernels) at the bench shape, bf16; used for
+A/B runs of kernel variants (tools/build_variant.sh + OSU_DREAMER_HIP_LIB).  usage: python tools/mb_bwd.py"""
 import math, os, sys, torch
 sys.path.insert(0, os.getcwd())
 from osu_dreamer_amd import ops
