@@ -48,7 +48,7 @@ int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, const 
  * replaces: attn.py:74-80. */
 int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                       int N, int K, const float* wq, const float* wk, const float* table, int L, int H, int hd, float eps,
-                      void* stream);
+                      float q_scale, void* stream);
 /* dW[N,K] (fp32, ld lddw) += G[M,N]^T A[M,K]; if dbias != NULL also dbias[N] += column sums of G
  * — autograd weight and bias gradients of the above, G read once. */
 int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M, int N,
@@ -111,21 +111,25 @@ int od_rmsnorm_gate_residual_bwd(int dtype, const void* h, int ldh, const float*
 /* ---- attention (common/attn.py:62-84) ------------------------------------------------ */
 /* table[l][j] = (cos, sin)(l * 10000^(-2j/hd)), fp32 [L][hd/2][2].  replaces: attn.py:18-24. */
 int od_rope_table(float* table, int L, int hd, void* stream);
-/* qk_out[m][0:2*dh] = rope(RMSNorm_hd(qkv[m][0:2*dh]) * w) per head.  replaces: attn.py:77-81. */
+/* qk_out[m][0:2*dh] = rope(RMSNorm_hd(qkv[m][0:2*dh]) * w) per head, the q heads multiplied by q_scale (1 = the
+ * reference's tensor; scale*log2(e) feeds od_flash_attn_* with q_prescaled = 1 and removes a multiply per score from
+ * their loops).  replaces: attn.py:77-81. */
 int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const float* wq, const float* wk, const float* table,
-                    void* qk_out, int ldo, int B, int L, int H, int hd, float eps, void* stream);
-/* dqkv[m][0:2*dh] from dqk (gradient wrt roped q,k); dwq/dwk[hd] += . */
+                    void* qk_out, int ldo, int B, int L, int H, int hd, float eps, float q_scale, void* stream);
+/* dqkv[m][0:2*dh] from dqk (gradient wrt the roped q * q_scale and the roped k); dwq/dwk[hd] += . */
 int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const float* wq, const float* wk, const float* table,
                         const void* dqk, int lddqk, void* dqkv, int lddqkv, float* dwq, float* dwk, int B, int L,
-                        int H, int hd, float eps, void* stream);
-/* o[m][h*hd+d] = softmax(q k^T * scale) v, non-causal, per (b,h); lse fp32 [B][H][L].
+                        int H, int hd, float eps, float q_scale, void* stream);
+/* q_prescaled != 0: q holds q * scale * log2(e) (od_qk_norm_rope's q_scale), the softmax is the same function of the
+ * unscaled q, and od_flash_attn_bwd returns dq as the gradient of that pre-multiplied tensor.
+ * o[m][h*hd+d] = softmax(q k^T * scale) v, non-causal, per (b,h); lse fp32 [B][H][L].
  * replaces: attn.py:82 (F.scaled_dot_product_attention). */
 int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo,
-                      float* lse, int B, int H, int L, int hd, float scale, void* stream);
+                      float* lse, int B, int H, int L, int hd, float scale, int q_prescaled, void* stream);
 /* dq,dk,dv from do; delta fp32 [B][H][L] is workspace. */
 int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                       int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk,
-                      int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, void* stream);
+                      int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled, void* stream);
 
 /* ---- SwiGLU feed-forward (common/swiglu.py:9-32) ------------------------------------- */
 /* y[b][l][c] = bias[c] + sum_j w[c][j] x[b][l+j-r][c], zero padded.  replaces: swiglu.py:20, model.py:59,62. */

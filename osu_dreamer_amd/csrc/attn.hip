@@ -105,7 +105,9 @@ __device__ __forceinline__ void st4(f32x3_t* p, float a, float b, float c, float
 
 // ======================================================================== forward
 // block: 4 waves x 32 query rows; loop over 64-key tiles, double-buffered in LDS.
-template <class T, int HD, int NW>
+// PRE: q arrives multiplied by scale*log2(e) (od_qk_norm_rope's q_scale), so q.k is already the base-2 exponent and
+// the per-element multiply disappears from the loop.
+template <class T, int HD, int NW, bool PRE>
 __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                            const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
                                                            float* __restrict__ lse, int B, int H, int L, float scale) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
     const T* kb = k + (size_t)b * L * ldk + h * HD;
     const T* vb = v + (size_t)b * L * ldv + h * HD;
     const int q0 = qt * QB + wave * 32;
-    const float c = scale * LOG2E;
+    const float c = PRE ? 1.f : scale * LOG2E;
 
     od_frag<T> fq[2][NS];
 #pragma unroll
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
                 f32x4 a = (f32x4)(-mref[qi]);
 #pragma unroll
                 for (int s = 0; s < NS; s++) a = od_mma(fk[s], fq[qi][s], a);
-                e[qi][t4] = a * c;                       // log2 units relative to the reference
+                if constexpr (PRE) e[qi][t4] = a; else e[qi][t4] = a * c;     // log2 units relative to the reference
             }
         }
         const int kbase = kt * 64;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 // dK, dV: block owns 4 waves x NK*16 keys; loop over 64-query tiles.
 //   S = Q K^T (cols = keys) ; dV^T += dO^T P ; dP = dO V^T ; dS = P*(dP - delta)*scale ; dK^T += Q^T dS
 // LDS per stage: Q, dO row-major (+ Q^T, dO^T for f32); bf16 double-buffers the stage.
-template <class T, int HD, int NK, int NWK>
+template <class T, int HD, int NK, int NWK, bool PRE>
 __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                                const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
@@ -333,7 +335,9 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
     // VALU diet: the score and dP accumulators START at -lse/scale and -delta (the MFMA's C operand), so
     // P = exp2(c * acc) and dS' = P * acc' need one packed multiply each — no fma/sub per element; the factor
     // `scale` of dS is applied once to dK at the end.
-    const float c = scale * LOG2E, inv_scale = 1.0f / scale;
+    // PRE (q pre-multiplied by scale*log2e): the accumulator starts at -lse*log2e and IS the exponent; dK then carries
+    // ln2 instead of scale (dL/dk = scale * sum dS q = ln2 * sum dS q').
+    const float c = scale * LOG2E, inv_scale = PRE ? LOG2E : 1.0f / scale, out_scale = PRE ? LN2 : scale;
 
     od_frag<T> fk[NK][NS], fv[NK][NS];
 #pragma unroll
@@ -422,7 +426,8 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
                 f32x4 sa = l4, pa = d4;
 #pragma unroll
                 for (int s = 0; s < NS; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
-                const f32x4 e = sa * c;
+                f32x4 e = sa;
+                if constexpr (!PRE) e = sa * c;
                 f32x4 p;
 #pragma unroll
                 for (int r = 0; r < 4; r++) p[r] = od_exp2(e[r]);
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
             T* dvr = dv + ((size_t)b * L + row) * lddv + h * HD;
 #pragma unroll
             for (int dt = 0; dt < ND; dt++) {
-                dkacc[ki][dt] *= scale;
+                dkacc[ki][dt] *= out_scale;
                 st4(dkr + dt * 16 + 4 * g, dkacc[ki][dt][0], dkacc[ki][dt][1], dkacc[ki][dt][2], dkacc[ki][dt][3]);
                 st4(dvr + dt * 16 + 4 * g, dvacc[ki][dt][0], dvacc[ki][dt][1], dvacc[ki][dt][2], dvacc[ki][dt][3]);
             }
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
 
 // dQ: block owns 4 waves x NQ*16 queries; loop over 64-key tiles.
 //   S^T = K Q^T ; dP^T = V dO^T ; dS^T = P^T*(dP^T - delta)*scale ; dQ^T += K^T dS^T
-template <class T, int HD, int NQ, int NW>
+template <class T, int HD, int NQ, int NW, bool PRE>
 __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                               const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
@@ -500,7 +505,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
     const T* vb = v + (size_t)b * L * ldv + h * HD;
     const T* dob = dout + (size_t)b * L * lddo + h * HD;
     const int q0 = qtile * QB + wave * NQ * 16;
-    const float c = scale * LOG2E, inv_scale = 1.0f / scale;     // accumulator-init trick, see the dK/dV kernel
+    // accumulator-init trick and PRE as in the dK/dV kernel; with PRE the result is the gradient of the pre-multiplied q
+    const float c = scale * LOG2E, inv_scale = PRE ? LOG2E : 1.0f / scale, out_scale = PRE ? LN2 : scale;
 
     od_frag<T> fq[NQ][NS], fdo[NQ][NS];
     float r_lse[NQ], r_del[NQ];
@@ -560,7 +566,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
                 f32x4 sa = (f32x4)(r_lse[qi]), pa = (f32x4)(r_del[qi]);
 #pragma unroll
                 for (int s = 0; s < NS; s++) { sa = od_mma(fkr[s], fq[qi][s], sa); pa = od_mma(fvr[s], fdo[qi][s], pa); }
-                const f32x4 e = sa * c;
+                f32x4 e = sa;
+                if constexpr (!PRE) e = sa * c;
                 f32x4 p;
 #pragma unroll
                 for (int r = 0; r < 4; r++) p[r] = od_exp2(e[r]);
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
             T* dqr = dq + ((size_t)b * L + row) * lddq + h * HD;
 #pragma unroll
             for (int dt = 0; dt < ND; dt++) {
-                dqacc[qi][dt] *= scale;
+                dqacc[qi][dt] *= out_scale;
                 st4(dqr + dt * 16 + 4 * g, dqacc[qi][dt][0], dqacc[qi][dt][1], dqacc[qi][dt][2], dqacc[qi][dt][3]);
             }
         }
@@ -607,18 +614,18 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
 #ifndef OD_ATTN_NW
 #define OD_ATTN_NW 4      // waves per workgroup of the bf16 forward / dQ kernels.  6 (K/V streamed once per 192 queries) measured 0.71x: a 6-wave group lands 2,2,1,1 on the SIMDs and a second group no longer fits at 3 waves/SIMD
 #endif
-template <class T, int HD>
+template <class T, int HD, bool PRE>
 int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* lse, int B,
                int H, int L, float scale, hipStream_t st) {
     constexpr int NW = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
     const int grid = attn_grid((L + NW * 32 - 1) / (NW * 32), B * H);
-    OD_LAUNCH_DYN((flash_fwd_kernel<T, HD, NW>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+    OD_LAUNCH_DYN((flash_fwd_kernel<T, HD, NW, PRE>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (T*)o, ldo, lse, B, H, L, scale);
     OD_CHECK_LAUNCH();
     return 0;
 }
 
-template <class T, int HD, int NK, int NQ>
+template <class T, int HD, int NK, int NQ, bool PRE>
 int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout,
                int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H,
                int L, float scale, hipStream_t st) {
@@ -630,11 +637,11 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 #endif
     constexpr int NWK = Stage<T, HD>::TR ? OD_DKV_NW : 4;
     const int gk = attn_grid((L + 16 * NWK * NK - 1) / (16 * NWK * NK), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK, NWK>), dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale);
     constexpr int NWQ = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
     const int gq = attn_grid((L + 16 * NQ * NWQ - 1) / (16 * NQ * NWQ), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ, NWQ>), dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale);
     OD_CHECK_LAUNCH();
     return 0;
@@ -643,21 +650,25 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 }  // namespace
 
 extern "C" int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
-                                 int ldo, float* lse, int B, int H, int L, int hd, float scale, void* stream) {
+                                 int ldo, float* lse, int B, int H, int L, int hd, float scale, int q_prescaled, void* stream) {
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8) return OD_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == OD_BF16 && hd == 64) return launch_fwd<bf16_t, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
-    if (dtype == OD_BF16 && hd == 32) return launch_fwd<bf16_t, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
-    if (dtype == OD_F32 && hd == 64) return launch_fwd<float, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
-    if (dtype == OD_F32 && hd == 32) return launch_fwd<float, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
-    if (dtype == OD_F32X3 && hd == 64) return launch_fwd<f32x3_t, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
-    if (dtype == OD_F32X3 && hd == 32) return launch_fwd<f32x3_t, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st);
+#define FWD(TT, HDV) (q_prescaled ? launch_fwd<TT, HDV, true>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st) \
+                                  : launch_fwd<TT, HDV, false>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st))
+    if (dtype == OD_BF16 && hd == 64) return FWD(bf16_t, 64);
+    if (dtype == OD_BF16 && hd == 32) return FWD(bf16_t, 32);
+    if (dtype == OD_F32 && hd == 64) return FWD(float, 64);
+    if (dtype == OD_F32 && hd == 32) return FWD(float, 32);
+    if (dtype == OD_F32X3 && hd == 64) return FWD(f32x3_t, 64);
+    if (dtype == OD_F32X3 && hd == 32) return FWD(f32x3_t, 32);
+#undef FWD
     return OD_ERR_UNSUPPORTED;
 }
 
 extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                                  int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq,
-                                 void* dk, int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, void* stream) {
+                                 void* dk, int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled,
+                                 void* stream) {
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
 #define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st
@@ -667,10 +678,12 @@ extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* 
 #ifndef OD_BWD_NQ
 #define OD_BWD_NQ 2
 #endif
-    if (dtype == OD_BF16 && hd == 64) return launch_bwd<bf16_t, 64, OD_BWD_NK, OD_BWD_NQ>(ARGS);
-    if (dtype == OD_BF16 && hd == 32) return launch_bwd<bf16_t, 32, 2, 2>(ARGS);
-    if (dtype == OD_F32 && hd == 64) return launch_bwd<float, 64, 1, 1>(ARGS);
-    if (dtype == OD_F32 && hd == 32) return launch_bwd<float, 32, 1, 1>(ARGS);
+#define BWD(TT, HDV, NKV, NQV) (q_prescaled ? launch_bwd<TT, HDV, NKV, NQV, true>(ARGS) : launch_bwd<TT, HDV, NKV, NQV, false>(ARGS))
+    if (dtype == OD_BF16 && hd == 64) return BWD(bf16_t, 64, OD_BWD_NK, OD_BWD_NQ);
+    if (dtype == OD_BF16 && hd == 32) return BWD(bf16_t, 32, 2, 2);
+    if (dtype == OD_F32 && hd == 64) return BWD(float, 64, 1, 1);
+    if (dtype == OD_F32 && hd == 32) return BWD(float, 32, 1, 1);
+#undef BWD
 #undef ARGS
     return OD_ERR_UNSUPPORTED;
 }

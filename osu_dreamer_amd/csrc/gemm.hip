@@ -81,7 +81,7 @@ __device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int& tm,
 // tile while it sits in LDS (a 128-column tile holds whole heads), the remaining columns (v) stored as they are.
 struct RopeEpi {
     const float* wq; const float* wk; const float* table;   // norm weights [hd], (cos, sin) table [L][hd/2][2]
-    int L, dh, hd, n_rope; float eps;                        // dh = H*hd (q columns), n_rope = 2*dh
+    int L, dh, hd, n_rope; float eps, q_scale;               // dh = H*hd (q columns), n_rope = 2*dh; q outputs * q_scale
 };
 constexpr int OD_EPI_QKROPE = 2;
 
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
                 od_ld8(bias + (gn < N ? n0 + pc * 8 : 0), pb);
                 const int d0 = (ch * 8) & (rp.hd - 1), dp = (pc * 8) & (rp.hd - 1);
                 const float* w = gn < rp.dh ? rp.wq : rp.wk;
+                const float invs = inv * (gn < rp.dh ? rp.q_scale : 1.f);
                 float wv[8], wp[8], t0[8], t1[8];                 // weights of own / partner chunk, 8 (cos, sin) pairs
                 od_ld8(w + d0, wv); od_ld8(w + dp, wp);
                 const float* tb = rp.table + ((size_t)((gm < M ? gm : 0) % rp.L) * half + (d0 & (half - 1))) * 2;
@@ -229,8 +230,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
                 const bool lo = d0 < half;
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    const float y = v[e] * inv * wv[e];
-                    const float yp = od_round_to<T>(pv[e] + pb[e]) * inv * wp[e];
+                    const float y = v[e] * invs * wv[e];
+                    const float yp = od_round_to<T>(pv[e] + pb[e]) * invs * wp[e];
                     const float cs = e < 4 ? t0[2 * e] : t1[2 * e - 8], sn = e < 4 ? t0[2 * e + 1] : t1[2 * e - 7];
                     v[e] = lo ? y * cs - yp * sn : yp * sn + y * cs;
                 }
@@ -751,13 +752,13 @@ extern "C" int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int 
 
 extern "C" int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                                  int M, int N, int K, const float* wq, const float* wk, const float* table, int L, int H, int hd,
-                                 float eps, void* stream) {
+                                 float eps, float q_scale, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !bias || !wq || !wk || !table || L <= 0) return OD_ERR_ARG;
     const int ch = dtype == OD_BF16 ? 8 : 4;
     if (lda % ch || ldw % ch || K % ch || N % 8 || ldc % 8) return OD_ERR_ALIGN;
     const int n_rope = 2 * H * hd;
     if ((hd != 32 && hd != 64) || n_rope % 128 || n_rope > N) return OD_ERR_UNSUPPORTED;
-    const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps};
+    const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps, q_scale};
     if (dtype == OD_BF16)
         return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
     if (dtype == OD_F32)

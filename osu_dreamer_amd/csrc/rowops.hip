@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256) void final_proj_bwd_kernel(const T* __restrict
 template <class T>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
                                                            const float* __restrict__ wk, const float* __restrict__ table,
-                                                           T* __restrict__ out, int ldo, int B, int L, int H, int hd, float eps) {
+                                                           T* __restrict__ out, int ldo, int B, int L, int H, int hd, float eps,
+                                                           float q_scale) {
     const int lane = threadIdx.x & 63;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= (long)B * L) return;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const T* __restrict__
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const float cs = tb[2 * e], sn = tb[2 * e + 1];
-                o[e] = first ? (y[e] * cs - p[e] * sn) : (p[e] * sn + y[e] * cs);
+                o[e] = (first ? (y[e] * cs - p[e] * sn) : (p[e] * sn + y[e] * cs)) * (slot < H ? q_scale : 1.f);
             }
             od_st8(out + m * ldo + (size_t)slot * hd + c8 * 8, o);
         }
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const T* __restri
                                                                const float* __restrict__ wk, const float* __restrict__ table,
                                                                const T* __restrict__ dqk, int lddqk, T* __restrict__ dqkv, int lddqkv,
                                                                float* __restrict__ dwq, float* __restrict__ dwk,
-                                                               int B, int L, int H, int hd, float eps) {
+                                                               int B, int L, int H, int hd, float eps, float q_scale) {
     __shared__ float sdw[2][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 512; i += 256) sdw[i >> 8][i & 255] = 0.f;
@@ -529,8 +530,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const T* __restri
             const bool act = q < nchunks;
             const int slot = q / lph, c8 = q % lph;
             float v[8], d[8];
-            if (act) { od_ld8(qkv + m * ldqkv + (size_t)slot * hd + c8 * 8, v); od_ld8(dqk + m * lddqk + (size_t)slot * hd + c8 * 8, d); }
-            else {
+            if (act) {
+                od_ld8(qkv + m * ldqkv + (size_t)slot * hd + c8 * 8, v); od_ld8(dqk + m * lddqk + (size_t)slot * hd + c8 * 8, d);
+                if (slot < H) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) d[e] *= q_scale;      // the forward scaled its q outputs
+                }
+            } else {
 #pragma unroll
                 for (int e = 0; e < 8; e++) { v[e] = 0.f; d[e] = 0.f; }
             }
@@ -590,7 +596,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const T* __restri
 template <class T, int HD>
 __global__ __launch_bounds__(256) void qk_norm_rope_head_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
                                                                 const float* __restrict__ wk, const float* __restrict__ table,
-                                                                T* __restrict__ out, int ldo, long M, int L, int H, float eps) {
+                                                                T* __restrict__ out, int ldo, long M, int L, int H, float eps,
+                                                                float q_scale) {
     constexpr int HALF = HD / 2;
     __shared__ float s_w[2][HD];
     __shared__ __attribute__((aligned(16))) float s_tab[64][HD];       // (cos,sin) x HALF per frame of the block
@@ -621,10 +628,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_head_kernel(const T* __restr
     const float inv = rsqrtf(ss / (float)HD + eps);
     const float* w = s_w[slot < H ? 0 : 1];
     const float* tb = s_tab[fr];
+    const float invs = inv * (slot < H ? q_scale : 1.f);
     float o[HD];
 #pragma unroll
     for (int j = 0; j < HALF; j++) {
-        const float y1 = v[j] * inv * w[j], y2 = v[j + HALF] * inv * w[j + HALF];
+        const float y1 = v[j] * invs * w[j], y2 = v[j + HALF] * invs * w[j + HALF];
         const float cs = tb[2 * j], sn = tb[2 * j + 1];
         o[j] = y1 * cs - y2 * sn;
         o[j + HALF] = y1 * sn + y2 * cs;
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_head_bwd_kernel(const T* __r
                                                                     const float* __restrict__ wk, const float* __restrict__ table,
                                                                     const T* __restrict__ dqk, int lddqk, T* __restrict__ dqkv, int lddqkv,
                                                                     float* __restrict__ dwq, float* __restrict__ dwk,
-                                                                    long M, int L, int H, float eps, int iters) {
+                                                                    long M, int L, int H, float eps, int iters, float q_scale) {
     constexpr int HALF = HD / 2;
     __shared__ float s_w[2][HD];
     __shared__ float s_dw[2][HD];
@@ -656,6 +664,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_head_bwd_kernel(const T* __r
     __syncthreads();
     const int slot = lane % nslot;
     const float* w = s_w[slot < H ? 0 : 1];
+    const float gs = slot < H ? q_scale : 1.f;        // the forward scaled its q outputs
     float acc[HD];
 #pragma unroll
     for (int d = 0; d < HD; d++) acc[d] = 0.f;
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_head_bwd_kernel(const T* __r
         for (int c = 0; c < HD / 8; c++) {
             float t8[8], g8[8]; od_ld8(src + c * 8, t8); od_ld8(gsrc + c * 8, g8);
 #pragma unroll
-            for (int e = 0; e < 8; e++) { v[c * 8 + e] = t8[e]; dy[c * 8 + e] = g8[e]; }
+            for (int e = 0; e < 8; e++) { v[c * 8 + e] = t8[e]; dy[c * 8 + e] = g8[e] * gs; }
         }
         float ss = 0.f;
 #pragma unroll
@@ -857,14 +866,14 @@ extern "C" int od_rope_table(float* table, int L, int hd, void* stream) {
 }
 
 extern "C" int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const float* wq, const float* wk, const float* table,
-                               void* qk_out, int ldo, int B, int L, int H, int hd, float eps, void* stream) {
+                               void* qk_out, int ldo, int B, int L, int H, int hd, float eps, float q_scale, void* stream) {
     if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
     if (ldqkv % 8 || ldo % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
     if (OD_QK_HEAD && (hd == 64 || hd == 32) && 64 % (2 * H) == 0 && H >= 2) {       // lane-per-head kernel (its LDS table holds 64 frames per block: 4 * 64/(2H) <= 64)
         const int rpw = 64 / (2 * H);
         dim3 g2((unsigned)((M + 4 * rpw - 1) / (4 * rpw)));
-#define QKH(TT, HDV) OD_LAUNCH((qk_norm_rope_head_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (TT*)qk_out, ldo, M, L, H, eps)
+#define QKH(TT, HDV) OD_LAUNCH((qk_norm_rope_head_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (TT*)qk_out, ldo, M, L, H, eps, q_scale)
         if (dtype == OD_BF16) { if (hd == 64) QKH(bf16_t, 64); else QKH(bf16_t, 32); }
         else { if (hd == 64) QKH(float, 64); else QKH(float, 32); }
 #undef QKH
@@ -874,24 +883,24 @@ extern "C" int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const floa
     dim3 grid((unsigned)((M + 3) / 4));
     if (dtype == OD_BF16)
         OD_LAUNCH((qk_norm_rope_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,
-                  (bf16_t*)qk_out, ldo, B, L, H, hd, eps);
+                  (bf16_t*)qk_out, ldo, B, L, H, hd, eps, q_scale);
     else
         OD_LAUNCH((qk_norm_rope_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, ldqkv, wq, wk, table,
-                  (float*)qk_out, ldo, B, L, H, hd, eps);
+                  (float*)qk_out, ldo, B, L, H, hd, eps, q_scale);
     OD_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const float* wq, const float* wk, const float* table,
                                    const void* dqk, int lddqk, void* dqkv, int lddqkv, float* dwq, float* dwk, int B, int L,
-                                   int H, int hd, float eps, void* stream) {
+                                   int H, int hd, float eps, float q_scale, void* stream) {
     if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
     if (ldqkv % 8 || lddqk % 8 || lddqkv % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
     if (OD_QK_HEAD && (hd == 64 || hd == 32) && 64 % (2 * H) == 0) {       // lane-per-head kernel
         const int rpw = 64 / (2 * H), iters = 16;
         dim3 g2((unsigned)((M + 4L * rpw * iters - 1) / (4L * rpw * iters)));
-#define QKHB(TT, HDV) OD_LAUNCH((qk_norm_rope_head_bwd_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (const TT*)dqk, lddqk, (TT*)dqkv, lddqkv, dwq, dwk, M, L, H, eps, iters)
+#define QKHB(TT, HDV) OD_LAUNCH((qk_norm_rope_head_bwd_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (const TT*)dqk, lddqk, (TT*)dqkv, lddqkv, dwq, dwk, M, L, H, eps, iters, q_scale)
         if (dtype == OD_BF16) { if (hd == 64) QKHB(bf16_t, 64); else QKHB(bf16_t, 32); }
         else { if (hd == 64) QKHB(float, 64); else QKHB(float, 32); }
 #undef QKHB
@@ -901,10 +910,10 @@ extern "C" int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const 
     dim3 grid((unsigned)((M + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD)));
     if (dtype == OD_BF16)
         OD_LAUNCH((qk_norm_rope_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,
-                  (const bf16_t*)dqk, lddqk, (bf16_t*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps);
+                  (const bf16_t*)dqk, lddqk, (bf16_t*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps, q_scale);
     else
         OD_LAUNCH((qk_norm_rope_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, ldqkv, wq, wk, table,
-                  (const float*)dqk, lddqk, (float*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps);
+                  (const float*)dqk, lddqk, (float*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps, q_scale);
     OD_CHECK_LAUNCH();
     return 0;
 }

@@ -56,6 +56,9 @@ class DenoiserEngine:
         self.Cg, self.D, self.U = a.global_cond_dim, a.backbone_dim, a.u_head_dim
         self.H, self.hd, self.depth = ba.n_heads, ba.head_dim, ba.depth
         self.dh = self.H * self.hd
+        # q leaves the norm + RoPE step multiplied by scale * log2(e): q.k is then the softmax's base-2 exponent and the
+        # attention loops drop one multiply per score (od_flash_attn_*'s q_prescaled mode)
+        self.q_scale = math.log2(math.e) / math.sqrt(self.hd)
         self.radius = ba.radius
         self.ksize = 1 + 2 * ba.radius
         self.Hf = int(self.D * ba.expand * 2 / 3)
@@ -197,16 +200,16 @@ class DenoiserEngine:
                 ops.gemm_nt(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv, x3=self.x3)
                 qk = self.lbuf("qk", i, (M, 2 * dh))         # backward needs the pre-norm q, k as well
                 ops.qk_norm_rope(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, qk,
-                                 B, L, self.H, self.hd, FP32_EPS)
+                                 B, L, self.H, self.hd, FP32_EPS, q_scale=self.q_scale)
             else:                                             # no-grad: norm + RoPE in the GEMM's epilogue, in place
                 ops.gemm_nt_qkrope(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv,
                                    self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, L,
-                                   self.H, self.hd, FP32_EPS, x3=self.x3)
+                                   self.H, self.hd, FP32_EPS, x3=self.x3, q_scale=self.q_scale)
                 qk = qkv
             y = self.lbuf("y", i, (M, dh))
             lse = self.lbuf("lse", i, (B, self.H, L), f32)
             ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, self.H, L, self.hd,
-                               1.0 / math.sqrt(self.hd), x3=self.x3)
+                               1.0 / math.sqrt(self.hd), x3=self.x3, q_prescaled=True)
             ao = self.lbuf("ao", i, (M, D))
             ops.gemm_nt(y, self.W(p + "attn.out_proj"), self.P(p + "attn.out_proj.bias"), ao, x3=self.x3)
             # --- gate + residual of the attention branch and norm + FiLM of the feed-forward branch, one pass
@@ -307,10 +310,11 @@ class DenoiserEngine:
             ops.gemm_nt(dbr, self.W(p + "attn.out_proj", T=True), None, dy)
             qk, qkv = t[f"qk.{i}"], t[f"qkv.{i}"]
             ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], t[f"y.{i}"], dy, t[f"lse.{i}"], delta,
-                               dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:], B, self.H, L, self.hd, 1.0 / math.sqrt(self.hd))
+                               dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:], B, self.H, L, self.hd, 1.0 / math.sqrt(self.hd),
+                               q_prescaled=True)
             ops.qk_norm_rope_bwd(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, dqk, dqkv,
                                  self.G(p + "attn.q_norm.weight"), self.G(p + "attn.k_norm.weight"), B, L, self.H,
-                                 self.hd, FP32_EPS)
+                                 self.hd, FP32_EPS, q_scale=self.q_scale)
             ops.gemm_tn(dqkv, t[f"h1.{i}"], self.G(p + "attn.qkv_proj.weight"), dbias=self.G(p + "attn.qkv_proj.bias"))
             ops.gemm_nt(dqkv, self.W(p + "attn.qkv_proj", T=True), None, dtmp)      # d h1 (== d cl)
             ops.gemm_tn(dtmp, a, self.G(p + "proj_cl.weight"), dbias=self.G(p + "proj_cl.bias"))

@@ -56,14 +56,14 @@ def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False, x3=False):
                           epilogue, int(accumulate), _stream(A))
 
 
-def gemm_nt_qkrope(A, W, bias, C, wq, wk, table, L, H, hd, eps, x3=False):
+def gemm_nt_qkrope(A, W, bias, C, wq, wk, table, L, H, hd, eps, x3=False, q_scale=1.0):
     """qkv projection with q/k RMSNorm + RoPE in the epilogue (forward-only): C[:, :2*H*hd] normed + rotated."""
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and tuple(C.shape) == (M, N) and A.dtype == W.dtype == C.dtype
     _f32(bias, wq, wk, table)
     _lib.lib().od_gemm_nt_qkrope(mm_code(A.dtype, x3), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
-                                 _p(wq), _p(wk), _p(table), L, H, hd, eps, _stream(A))
+                                 _p(wq), _p(wk), _p(table), L, H, hd, eps, q_scale, _stream(A))
 
 
 def gemm_tn(G, A, dW, n_cols=None, k_cols=None, dbias=None):
@@ -187,29 +187,29 @@ def rope_table(table, L, hd):
     _lib.lib().od_rope_table(_p(table), L, hd, _stream(table))
 
 
-def qk_norm_rope(qkv, wq, wk, table, qk_out, B, L, H, hd, eps):
+def qk_norm_rope(qkv, wq, wk, table, qk_out, B, L, H, hd, eps, q_scale=1.0):
     _f32(wq, wk, table)
     _lib.lib().od_qk_norm_rope(dt_code(qkv.dtype), _p(qkv), _ld(qkv), _p(wq), _p(wk), _p(table), _p(qk_out),
-                               _ld(qk_out), B, L, H, hd, eps, _stream(qkv))
+                               _ld(qk_out), B, L, H, hd, eps, q_scale, _stream(qkv))
 
 
-def qk_norm_rope_bwd(qkv, wq, wk, table, dqk, dqkv, dwq, dwk, B, L, H, hd, eps):
+def qk_norm_rope_bwd(qkv, wq, wk, table, dqk, dqkv, dwq, dwk, B, L, H, hd, eps, q_scale=1.0):
     _f32(wq, wk, table, dwq, dwk)
     _lib.lib().od_qk_norm_rope_bwd(dt_code(qkv.dtype), _p(qkv), _ld(qkv), _p(wq), _p(wk), _p(table), _p(dqk), _ld(dqk),
-                                   _p(dqkv), _ld(dqkv), _p(dwq), _p(dwk), B, L, H, hd, eps, _stream(qkv))
+                                   _p(dqkv), _ld(dqkv), _p(dwq), _p(dwk), B, L, H, hd, eps, q_scale, _stream(qkv))
 
 
-def flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale, x3=False):
+def flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale, x3=False, q_prescaled=False):
     _f32(lse)
     _lib.lib().od_flash_attn_fwd(mm_code(q.dtype, x3), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(lse),
-                                 B, H, L, hd, scale, _stream(q))
+                                 B, H, L, hd, scale, int(q_prescaled), _stream(q))
 
 
-def flash_attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, L, hd, scale):
+def flash_attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, L, hd, scale, q_prescaled=False):
     _f32(lse, delta)
     _lib.lib().od_flash_attn_bwd(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(do),
                                  _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv),
-                                 B, H, L, hd, scale, _stream(q))
+                                 B, H, L, hd, scale, int(q_prescaled), _stream(q))
 
 
 # ---------------------------------------------------------------- feed-forward

@@ -53,13 +53,13 @@ def test_gemm_nt_qkrope_equals_gemm_then_rope(dev, dtype, H, hd, L, B, K):
     qkv = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
     ops.gemm_nt(A, W, b, qkv)
     qk = torch.zeros(M, 2 * dh, dtype=dtype, device=dev)
-    ops.qk_norm_rope(qkv, wq, wk, tab, qk, B, L, H, hd, eps)
+    ops.qk_norm_rope(qkv, wq, wk, tab, qk, B, L, H, hd, eps, q_scale=0.18)
     fused = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
-    ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps)
+    ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps, q_scale=0.18)
     assert torch.equal(fused[:, 2 * dh:], qkv[:, 2 * dh:])                      # v columns untouched
     assert rel_l2(fused[:, :2 * dh].float(), qk.float()) < (2e-6 if dtype == torch.float32 else 3e-3)
     if dtype == torch.float32:
-        ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps, x3=True)
+        ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps, x3=True, q_scale=0.18)
         assert rel_l2(fused[:, :2 * dh], qk) < 2e-5
 
 
@@ -259,7 +259,8 @@ def test_rmsnorm_film_and_gate(dev, dtype, C, bcast):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("H,hd", [(2, 32), (16, 64), (3, 16)])
-def test_qk_norm_rope(dev, dtype, H, hd):
+@pytest.mark.parametrize("q_scale", [1.0, 0.18])        # 1: the reference's tensor; scale*log2(e): what the engine feeds attention
+def test_qk_norm_rope(dev, dtype, H, hd, q_scale):
     g = torch.Generator().manual_seed(7)
     B, L = 2, 19
     M, dh = B * L, H * hd
@@ -272,11 +273,11 @@ def test_qk_norm_rope(dev, dtype, H, hd):
     assert rel_l2(table[..., 0], ang.cos()) < 1e-5 and rel_l2(table[..., 1], ang.sin()) < 1e-5
     out = torch.zeros(M, 2 * dh, dtype=dtype, device=dev)
     eps = torch.finfo(torch.float32).eps
-    ops.qk_norm_rope(qkv, wq, wk, table, out, B, L, H, hd, eps)
+    ops.qk_norm_rope(qkv, wq, wk, table, out, B, L, H, hd, eps, q_scale=q_scale)
 
     def ref_fn(qkvr, wqr, wkr):
         t = qkvr.reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)   # (3,B,H,L,hd)
-        q = O.rope_half_split(O.head_rms_norm(t[0], wqr))
+        q = O.rope_half_split(O.head_rms_norm(t[0], wqr)) * q_scale
         k = O.rope_half_split(O.head_rms_norm(t[1], wkr))
         return torch.stack([q, k], 0).permute(1, 3, 0, 2, 4).reshape(M, 2 * dh)
     qr, wqr, wkr = leaf(qkv), leaf(wq), leaf(wk)
@@ -286,7 +287,7 @@ def test_qk_norm_rope(dev, dtype, H, hd):
     ref.backward(dqk.float().cpu())
     dqkv = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
     dwq, dwk = torch.zeros(hd, device=dev), torch.zeros(hd, device=dev)
-    ops.qk_norm_rope_bwd(qkv, wq, wk, table, dqk, dqkv, dwq, dwk, B, L, H, hd, eps)
+    ops.qk_norm_rope_bwd(qkv, wq, wk, table, dqk, dqkv, dwq, dwk, B, L, H, hd, eps, q_scale=q_scale)
     assert rel_l2(dqkv.float()[:, :2 * dh], qr.grad[:, :2 * dh]) < TOL[dtype]
     assert rel_l2(dwq, wqr.grad) < TOL[dtype] and rel_l2(dwk, wkr.grad) < TOL[dtype]
 
@@ -343,6 +344,22 @@ def test_flash_attention(dev, dtype, B, H, L, hd):
     assert rel_l2(dv.float(), vr.grad) < tol
     assert rel_l2(dk.float(), kr.grad) < tol
     assert rel_l2(dq.float(), qr.grad) < tol
+    # q_prescaled: q' = q * scale * log2(e) handed over instead of q; same softmax, dq returned for q'
+    c = scale * math.log2(math.e)
+    qp = (q.float() * c).to(dtype).contiguous()
+    qs = leaf(qp.float() / c)                                   # the q that q' stands for
+    kr2, vr2 = leaf(k), leaf(v)
+    s2 = heads(qs) @ heads(kr2).transpose(-1, -2) * scale
+    ref2 = (torch.softmax(s2, -1) @ heads(vr2)).permute(0, 2, 1, 3).reshape(M, dh)
+    o2, lse2 = torch.zeros_like(o), torch.zeros_like(lse)
+    ops.flash_attn_fwd(qp, k, v, o2, lse2, B, H, L, hd, scale, q_prescaled=True)
+    assert rel_l2(o2.float(), ref2) < TOL[dtype]
+    assert rel_l2(lse2, torch.logsumexp(s2, -1)) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+    ref2.backward(do.float().cpu())
+    dq2, dk2, dv2 = (torch.zeros(M, dh, dtype=dtype, device=dev) for _ in range(3))
+    ops.flash_attn_bwd(qp, k, v, o2, do, lse2, delta, dq2, dk2, dv2, B, H, L, hd, scale, q_prescaled=True)
+    assert rel_l2(dv2.float(), vr2.grad) < tol and rel_l2(dk2.float(), kr2.grad) < tol
+    assert rel_l2(dq2.float(), qs.grad / c) < tol
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
