@@ -100,10 +100,10 @@ def roofline_of_dominant_kernel(tr, B, L):
 
     def bwd():
         ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
-                           dqkv[:, 2 * dh:], B, H, L, hd, scale)
+                           dqkv[:, 2 * dh:], B, H, L, hd, scale, q_prescaled=True)     # as the step launches it
 
     def fwd():
-        ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, H, L, hd, scale)
+        ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, H, L, hd, scale, q_prescaled=True)
     unit = 2.0 * B * H * L * L * hd                 # one L x L x hd MFMA pass over all heads
     t_bwd, t_fwd = time_kernel(bwd), time_kernel(fwd)
     # od_flash_attn_bwd = delta + dK/dV kernel (4 passes) + dQ kernel (3 passes); fwd = 2 passes
