@@ -199,35 +199,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
     if constexpr (EPI == OD_EPI_QKROPE) {
         // (launcher guarantees N % 8 == 0, ldc % 8 == 0, n_rope % 128 == 0, hd in {32, 64}, bias != null)
         const int half = rp.hd >> 1, lph = rp.hd >> 3;          // lanes (8-column chunks) per head
+        // a thread keeps its 8-column chunk (tid & 15) over the rows it walks: bias, norm weights and chunk geometry
+        // are loaded once, only the frame's (cos, sin) row changes
+        const int ch = tid & 15, gn = n0 + ch * 8;
+        const bool roped = n0 < rp.n_rope;                      // block-uniform
+        const int pc = ch ^ (lph >> 1);                         // chunk holding the rotary partners (d +- hd/2)
+        const int d0 = (ch * 8) & (rp.hd - 1), dp = (pc * 8) & (rp.hd - 1);
+        const bool lo = d0 < half;
+        float bv[8], pb[8], wv[8], wp[8];
+        od_ld8(bias + (gn < N ? gn : 0), bv);
+        od_ld8(bias + (gn < N ? n0 + pc * 8 : 0), pb);
+        {
+            const float* w = gn < rp.dh ? rp.wq : rp.wk;
+            od_ld8(w + d0, wv); od_ld8(w + dp, wp);
+        }
+        const float qs = gn < rp.dh ? rp.q_scale : 1.f;
 #pragma unroll
         for (int i = 0; i < 2 * WMT; i++) {
-            const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-            const int gm = m0 + row, gn = n0 + ch * 8;
+            const int row = (tid + 256 * i) >> 4;
+            const int gm = m0 + row;
             const bool valid = gm < M && gn < N;
-            const bool roped = n0 < rp.n_rope;                  // block-uniform
-            float v[8], bv[8];
+            float v[8];
             od_ld8(sC + row * 128 + ch * 8, v);
-            od_ld8(bias + (gn < N ? gn : 0), bv);
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = od_round_to<T>(v[e] + bv[e]);   // what the unfused path reads back from qkv
             if (roped) {
+                float t0[8], t1[8], pv[8];                        // the frame's 8 (cos, sin) pairs, partner values
+                const float* tb = rp.table + ((size_t)((gm < M ? gm : 0) % rp.L) * half + (d0 & (half - 1))) * 2;
+                od_ld8(tb, t0); od_ld8(tb + 8, t1);
+                od_ld8(sC + row * 128 + pc * 8, pv);
                 float ss = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; e++) ss += v[e] * v[e];
                 for (int msk = 1; msk < lph; msk <<= 1) ss += __shfl_xor(ss, msk);
-                const float inv = rsqrtf(ss / (float)rp.hd + rp.eps);
-                const int pc = ch ^ (lph >> 1);                 // chunk holding the rotary partners (d +- hd/2)
-                float pv[8], pb[8];
-                od_ld8(sC + row * 128 + pc * 8, pv);
-                od_ld8(bias + (gn < N ? n0 + pc * 8 : 0), pb);
-                const int d0 = (ch * 8) & (rp.hd - 1), dp = (pc * 8) & (rp.hd - 1);
-                const float* w = gn < rp.dh ? rp.wq : rp.wk;
-                const float invs = inv * (gn < rp.dh ? rp.q_scale : 1.f);
-                float wv[8], wp[8], t0[8], t1[8];                 // weights of own / partner chunk, 8 (cos, sin) pairs
-                od_ld8(w + d0, wv); od_ld8(w + dp, wp);
-                const float* tb = rp.table + ((size_t)((gm < M ? gm : 0) % rp.L) * half + (d0 & (half - 1))) * 2;
-                od_ld8(tb, t0); od_ld8(tb + 8, t1);
-                const bool lo = d0 < half;
+                const float invs = rsqrtf(ss / (float)rp.hd + rp.eps) * qs;
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const float y = v[e] * invs * wv[e];
