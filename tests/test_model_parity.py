@@ -162,3 +162,41 @@ def test_full_width_vs_reference(name):
     _lib._lib = None
     _lib.lib()
     run_case(name, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("B,L,Ba,steps", [(1, 5, 1, 1), (2, 64, 2, 3), (3, 129, 1, 2), (1, 200, 1, 5)])
+def test_edge_shapes_vs_oracle(dev, B, L, Ba, steps):
+    """Shapes the fixtures do not hold — a sequence shorter than one attention tile, exact tile multiples, one past a
+    multiple, batch 1, a single sampler step (no captured loop) — against the oracle (itself pinned by the fixtures):
+    forward, sampler, loss and every gradient."""
+    d = O.TINY
+    P = O.init_params(d, seed=900 + L)
+    data = O.synthetic_batch(d, B, L, seed=901 + L)
+    g = torch.Generator().manual_seed(902 + L)
+    h = data["h"][:Ba]
+    xt = torch.randn(B, d.emb_dim, L, generator=g)
+    x_init = torch.randn(B, d.emb_dim, L, generator=g)
+    m = DiffusionModel(d.emb_dim, d.a_dim, d.style_dim, margs(d))
+    m.load_state_dict(P)
+    m = m.to(dev)
+    with torch.no_grad():
+        u, v = m(h.to(dev), data["s"].to(dev), xt.to(dev))
+    ref_u, ref_v = O.forward(h, data["s"], xt, P, d)
+    assert rel_l2(u, ref_u) < 1e-5 and rel_l2(v, ref_v) < 5e-5
+    xs = m.sample(h.to(dev), data["s"].to(dev), steps, x_init=x_init.to(dev))
+    ref_x = O.sample(h, data["s"], steps, x_init, P, d)[0]
+    assert rel_l2(xs, ref_x) < 1e-4
+    if Ba == B:       # training never broadcasts audio
+        tr = DiffusionTrainer(val_batches=2, opt_args=dict(lr=3e-4, weight_decay=0.01),
+                              schedule_args=LRScheduleArgs(warmup_init=.3, warmup_steps=1000, decay_start=30000),
+                              osl_weight=1., del_weight=30., emb_dim=d.emb_dim, a_dim=d.a_dim, style_dim=d.style_dim,
+                              diffusion_args=margs(d))
+        tr.diffusion.load_state_dict(P)
+        tr = tr.to(dev)
+        loss, _ = tr(tr.diffusion, data["h"].to(dev), data["z"].to(dev), data["s"].to(dev), None, t=data["t"].to(dev),
+                     x0=data["x0"].to(dev))
+        loss.backward()
+        ref_loss, _, ref_grads = O.loss_and_grads(P, d, data["h"], data["z"], data["s"], data["t"], data["x0"])
+        assert float(loss.detach()) == pytest.approx(float(ref_loss), rel=5e-5)
+        for k, p in tr.diffusion.named_parameters():
+            assert rel_l2(p.grad, ref_grads[k]) < 1e-3, k
