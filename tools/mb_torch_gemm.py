@@ -15,3 +15,14 @@ for M in (262144, 4460):
         t_own = timeit(lambda: ops.gemm_nt(A, W, bias, C), it)
         fl = 2.0 * M * N * K / 1e9
         print(f"M={M:7d} {name:7s} N={N:5d} K={K:5d}  torch.matmul {t_lib:8.3f} ms {fl / t_lib:7.1f} TF/s | od_gemm_nt {t_own:8.3f} ms {fl / t_own:7.1f} TF/s")
+
+print("# weight-gradient shapes: dW[N,K] = G[M,N]^T A[M,K], M = 262144")
+M = 262144
+for name, N, K in (("qkv", 3072, 512), ("out", 512, 1024), ("vg", 2816, 512), ("proj_o", 512, 1408)):
+    G = torch.randn(M, N, device=dev).to(bf); A = torch.randn(M, K, device=dev).to(bf)
+    dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+    out = torch.empty(N, K, dtype=bf, device=dev)
+    t_lib = timeit(lambda: torch.matmul(G.t(), A, out=out), 5)
+    t_own = timeit(lambda: ops.gemm_tn(G, A, dW, dbias=db), 5)
+    fl = 2.0 * M * N * K / 1e9
+    print(f"M={M:7d} {name:7s} N={N:5d} K={K:5d}  torch.matmul(G^T A) {t_lib:8.3f} ms {fl / t_lib:7.1f} TF/s | od_gemm_tn (+bias grad, fp32 out) {t_own:8.3f} ms {fl / t_own:7.1f} TF/s")
