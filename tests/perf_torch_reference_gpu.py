@@ -66,3 +66,23 @@ torch.cuda.synchronize()
 ms = (time.time() - t0) / n * 1e3
 print(f"torch-eager reference algorithm on cuda:0, bf16 autocast, B={B} L={L}: {ms:.1f} ms/step "
       f"({1e3 / ms:.3f} steps/s), peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB, loss {float(loss):.4f}")
+
+# ---- sampler (BASELINE configs[3]): 50 steps, 4 difficulties, L = 1115, audio batch 1
+if len(sys.argv) <= 1:
+    del P, ema, opt, data
+    torch.cuda.empty_cache()
+    Ps = {k: v.to(dev) for k, v in O.init_params(d, seed=5).items()}
+    g = torch.Generator().manual_seed(5)
+    Bs, Ls = 4, 1115
+    h = torch.randn(1, d.a_dim, Ls, generator=g).to(dev)
+    s_ = torch.randn(Bs, d.style_dim, generator=g).to(dev)
+    x_init = torch.randn(Bs, d.emb_dim, Ls, generator=g).to(dev)
+    for name, ctx in (("fp32", torch.autocast("cuda", enabled=False)), ("bf16 autocast", torch.autocast("cuda", dtype=torch.bfloat16))):
+        with torch.no_grad(), ctx:
+            O.sample(h, s_, 50, x_init, Ps, d)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            O.sample(h, s_, 50, x_init, Ps, d)
+            torch.cuda.synchronize()
+        dt = time.time() - t0
+        print(f"torch-eager reference sampler on cuda:0, {name}, 50 steps B={Bs} L={Ls}: {dt * 1e3:.1f} ms ({Bs * Ls / dt:.0f} latents/s)")
