@@ -2,6 +2,7 @@
 """Benchmark of the denoiser hot path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W        # starts the N ranks itself (torchrun children)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Step = one training step of BASELINE.json configs[1] per GPU: batch 32 x 8192-frame synthetic
@@ -86,9 +87,34 @@ def time_kernel(fn, iters=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+BWD_PASSES_ALGORITHMIC = 5     # S = QK^T recompute, dP = dO V^T, dV = P^T dO, dK = dS^T Q, dQ = dS K  (backward = 2x forward + recompute)
+
+
+def bwd_passes_executed():
+    """MFMA passes od_flash_attn_bwd actually issues (5 for the single-kernel backward; 7 when dK/dV and dQ are separate
+    kernels that each recompute S and dP)."""
+    from osu_dreamer_amd import _lib
+    return int(_lib.lib().cdll.od_flash_attn_bwd_passes())
+
+
+def load_traffic(B, L):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of THIS round's kernels (profiles/r02_traffic.json,
+    written by tools/rocpd_pmc.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs: counters cannot be read in-process)."""
+    try:
+        tr_ = json.load(open(os.path.join(REPO, "profiles", "r02_traffic.json")))
+        if (B, L) == (tr_.get("B"), tr_.get("L")):
+            e = tr_["od_flash_attn_bwd"]
+            return int(e["read_bytes"] + e["write_bytes"])
+    except Exception:
+        pass
+    return None
+
+
 def roofline_of_dominant_kernel(tr, B, L):
-    """Re-launch the step's dominant kernel (flash-attention backward dK/dV, 4 of the 9 attention
-    MFMA passes per layer) alone on the step's own buffers and time it with HIP events."""
+    """Re-launch the step's dominant kernel (od_flash_attn_bwd: the attention backward of one layer) alone on the step's
+    own buffers and time it with HIP events on the launch stream.  `achieved` counts ALGORITHMIC FLOPs: 5 MFMA passes of
+    2*B*H*L^2*hd each (flash attention's backward with the score recompute); the passes actually executed are reported
+    separately."""
     from osu_dreamer_amd import ops
     eng = tr.diffusion.engine
     t = eng.ws.t
@@ -99,33 +125,36 @@ def roofline_of_dominant_kernel(tr, B, L):
     scale = 1 / math.sqrt(hd)
 
     def bwd():
-        ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
-                           dqkv[:, 2 * dh:], B, H, L, hd, scale, q_prescaled=True)     # as the step launches it
+        eng.attn_bwd_launch(qk, qkv, y, dy, lse, delta, dqk, dqkv)       # exactly as the step launches it
 
     def fwd():
         ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, H, L, hd, scale, q_prescaled=True)
     unit = 2.0 * B * H * L * L * hd                 # one L x L x hd MFMA pass over all heads
     t_bwd, t_fwd = time_kernel(bwd), time_kernel(fwd)
-    # od_flash_attn_bwd = delta + dK/dV kernel (4 passes) + dQ kernel (3 passes); fwd = 2 passes
-    ach_bwd = 7 * unit / t_bwd / 1e12
+    executed = bwd_passes_executed()
+    ach_bwd = BWD_PASSES_ALGORITHMIC * unit / t_bwd / 1e12
     ach_fwd = 2 * unit / t_fwd / 1e12
-    # HBM bytes per launch are PMC measurements from a separate rocprofv3 pass (FETCH_SIZE x2 + WRITE_SIZE,
-    # profiles/r01_traffic.json); they cannot be collected from inside this process.
-    traffic = None
-    try:
-        tr_ = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
-        if (B, L) == (32, 8192):
-            traffic = tr_["od_flash_attn_bwd"]["read_bytes"] + tr_["od_flash_attn_bwd"]["write_bytes"]
-    except Exception:
-        pass
     return {
-        "bound": "mfma", "kernel": "flash_bwd_dkv_kernel+flash_bwd_dq_kernel (od_flash_attn_bwd)",
+        "bound": "mfma", "kernel": "od_flash_attn_bwd (attention backward of one layer)",
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(B, L),
         "ms_per_launch": round(t_bwd * 1e3, 3),
+        "flops_counted": f"algorithmic: {BWD_PASSES_ALGORITHMIC} passes x 2*B*H*L^2*hd",
+        "mfma_passes_executed": executed,
+        "achieved_executed": round(executed * unit / t_bwd / 1e12, 1),
         "also": {"od_flash_attn_fwd": {"achieved": round(ach_fwd, 1), "frac": round(ach_fwd / PEAK_BF16_TFLOPS, 4),
                                        "ms_per_launch": round(t_fwd * 1e3, 3)}},
     }
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(L_cpu=2048):
@@ -148,7 +177,7 @@ def cpu_baseline(L_cpu=2048):
     dt = time.time() - t0
     frames_per_s = L_cpu / dt
     return {"value": frames_per_s / (32 * 8192), "unit": "train-steps/s (32x8192-frame step equivalent)",
-            "cores": cores, "kind": "port",
+            "cores": cores, "cpu": cpu_model(), "kind": "port",
             "sample": f"1 fp32 train step, batch 1 x {L_cpu} frames, {dt:.1f} s, {frames_per_s:.0f} frames/s; "
                       f"attention cost grows with L, so this over-states the CPU rate at L=8192"}
 
@@ -262,7 +291,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / sampler legs")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # --gpus N: one process per GPU.  Outside a torchrun job this process only starts the N ranks (as children,
+    # before anything here touches the GPU) and hands back their exit code.
+    from osu_dreamer_amd import launch
+    rc = launch.spawn_ranks_if_needed(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
+    world = launch.check_world(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -278,16 +313,17 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
+        assert dist.get_world_size() == world == args.gpus or os.environ.get("OD_FORCE_DDP") == "1"
     B, L = args.batch, args.frames
     tr = make_trainer(device, seed=1234)
     tr.diffusion.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if ddp:
-        from osu_dreamer_amd.ddp import GradBucketReducer
-        reducer = GradBucketReducer(tr.diffusion)
-        reducer.broadcast_parameters(0)
-    batch = synthetic_batch(B, L, device, seed=1234 + rank)
     cfg = tr.configure_optimizers()
     opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    if ddp:
+        from osu_dreamer_amd.ddp import GradBucketReducer
+        reducer = GradBucketReducer(tr.diffusion)          # RCCL communicator through the C ABI (od_comm_*)
+        reducer.broadcast_state(opt, tr.diffusion_ema, src=0)
+    batch = synthetic_batch(B, L, device, seed=1234 + rank)
 
     def step(i):
         opt.zero_grad()
@@ -323,17 +359,21 @@ def main():
         ms = dt / args.steps * 1e3
         frames = B * L
         f_fwd = flops_forward(frames, L)
-        # executed MFMA work: forward + 2x GEMM backward + attention backward as 7 passes (vs 2 forward)
+        # executed MFMA work: forward + 2x GEMM backward + attention backward as its executed passes (vs 2 forward)
         attn_fwd = frames * 32_768 * L
-        executed = f_fwd + 2 * (f_fwd - attn_fwd) + 3.5 * attn_fwd
+        executed = f_fwd + 2 * (f_fwd - attn_fwd) + bwd_passes_executed() / 2 * attn_fwd
+        named = {(32, 8192): "BASELINE.json configs[1]", (8, 32768): "BASELINE.json configs[4] shape, bf16 compute",
+                 (2, 4096): "BASELINE.json configs[0] shape, on the GPU"}.get((B, L), "custom --batch/--frames")
+        if world > 1 and (B, L) == (32, 8192):
+            named = f"BASELINE.json configs[2] pattern at {world} ranks (configs[1] per rank)"
         line = {
             "metric": "denoiser train-steps/sec + 50-step sample latents/sec, 1/2/4/8 MI355X",
             "value": round(world * args.steps / dt, 4), "unit": f"train-steps/s (rank-steps of batch {B} x {L} frames)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"single-GPU denoiser training, batch={B}, {L}-frame synthetic latents, {args.dtype} "
-                                   "(BASELINE.json configs[1]); per-rank batch fixed under --gpus N",
+            "config": {"workload": f"denoiser training step, batch={B} per GPU, {L}-frame synthetic latents, {args.dtype} "
+                                   f"({named}); per-rank batch fixed under --gpus N",
                        "per_gpu_batch": B, "global_batch": B * world, "frames": L, "params": 46_877_103,
                        "parallelism": f"dp{world}"},
             "frames_per_s": round(world * frames * args.steps / dt, 1),
@@ -344,6 +384,10 @@ def main():
             "final_loss": round(final_loss, 4),
             "workspace_gb": round(tr.diffusion.engine.ws.bytes / 2**30, 1),
         }
+        if ddp:
+            line["collective"] = {"backend": "RCCL via od_allreduce_grads", "version": reducer.comm.version,
+                                  "exchange": "od_allreduce_grads per arena segment (187.5 MB fp32 per step), overlapped with backward",
+                                  "world_size": world}
         if not args.no_extras and world == 1:
             line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
             line["forward_64x8192"] = forward_target_shape(tr, device)
@@ -355,6 +399,7 @@ def main():
     if ddp:
         import torch.distributed as dist
         dist.barrier()
+        reducer.close()
         dist.destroy_process_group()      # RCCL prints its banner here: keep the JSON the LAST line
     if line is not None:
         sys.stdout.flush()

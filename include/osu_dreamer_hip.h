@@ -31,7 +31,7 @@ enum { OD_F32 = 0, OD_BF16 = 1,
        OD_F32X3 = 2 };
 enum { OD_EPI_NONE = 0, OD_EPI_SILU = 1 };
 enum { OD_ACT_NONE = 0, OD_ACT_SILU = 1 };
-enum { OD_ERR_ARG = -1, OD_ERR_ALIGN = -2, OD_ERR_UNSUPPORTED = -3 };
+enum { OD_ERR_ARG = -1, OD_ERR_ALIGN = -2, OD_ERR_UNSUPPORTED = -3, OD_ERR_COMM = -4 };
 
 int od_version(void);
 const char* od_error_string(int code);
@@ -130,6 +130,9 @@ int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* k, int ldk,
 int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                       int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk,
                       int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled, void* stream);
+/* L x L x hd MFMA passes one od_flash_attn_bwd call issues for bf16 (the algorithmic minimum with the score recompute is 5);
+ * bench.py reports it next to the algorithmic roofline figure. */
+int od_flash_attn_bwd_passes(void);
 
 /* ---- SwiGLU feed-forward (common/swiglu.py:9-32) ------------------------------------- */
 /* y[b][l][c] = bias[c] + sum_j w[c][j] x[b][l+j-r][c], zero padded.  replaces: swiglu.py:20, model.py:59,62. */
@@ -239,6 +242,26 @@ int od_chart_head(int dtype, const void* x, int ldx, const float* W, const float
  * replaces: AttnPool.forward, latent/model.py:33-36 (the two 1x1 convs before it are od_gemm_nt). */
 int od_attn_pool(int dtype, const void* scores, int lds, const void* values, int ldv, float* out, int B, int L, int Hh, int hd,
                  void* stream);
+
+/* ---- data-parallel exchange: RCCL over xGMI (no counterpart in the reference, which is
+ *      single-device, models/diffusion/model.yml:11 `devices: 1`) ------------------------------------------------- */
+/* Bind RCCL at run time: dlopen(path), or "librccl.so.1" when path is NULL/empty.  A host process that already holds an
+ * RCCL instance (PyTorch's torch/lib/librccl.so) passes that path so both share one library.  Called implicitly (with the
+ * default) by the entry points below if it was not called before. */
+int od_comm_load(const char* path);
+/* ncclGetVersion() of the bound library (e.g. 22606), 0 if none could be bound. */
+int od_comm_version(void);
+/* rank 0: fill out[nbytes = 128] with a fresh ncclUniqueId (host memory); the host ships it to the other ranks. */
+int od_comm_unique_id(void* out, int nbytes);
+/* every rank: *comm_out = communicator of `nranks` ranks built from the shared 128-byte id (ncclCommInitRank on the
+ * current device). */
+int od_comm_init(void** comm_out, int nranks, int rank, const void* unique_id, int nbytes);
+int od_comm_destroy(void* comm);
+/* grads[0:count] (fp32, device) <- sum over ranks (average != 0: mean) in place, enqueued on `stream`: the one exchange
+ * of a data-parallel training step (the gradient of train.py:120-123's loss over the global batch). */
+int od_allreduce_grads(void* comm, float* grads, long count, int average, void* stream);
+/* buf[0:count] (fp32, device) <- rank `root`'s copy: parameters, AdamW moments and the EMA at start-up / resume. */
+int od_broadcast_f32(void* comm, float* buf, long count, int root, void* stream);
 
 /* ---- hipGraph helpers for the captured sampler loop ---------------------------------- */
 int od_graph_begin(void* stream);

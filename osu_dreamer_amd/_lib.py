@@ -25,6 +25,7 @@ _CTYPES = {
     "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
     "float*": ctypes.c_void_p, "const float*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "void**": ctypes.POINTER(ctypes.c_void_p),
+    "const char*": ctypes.c_char_p,
 }
 
 

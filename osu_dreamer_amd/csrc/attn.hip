@@ -665,6 +665,8 @@ extern "C" int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* 
     return OD_ERR_UNSUPPORTED;
 }
 
+extern "C" int od_flash_attn_bwd_passes(void) { return 7; }   // dK/dV kernel: S, dP, dV, dK; dQ kernel: S, dP, dQ
+
 extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                                  int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq,
                                  void* dk, int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled,

@@ -3,19 +3,27 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libosudreamer_hip.so
-SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip style.hip latent.hip"
+SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip style.hip latent.hip comm.hip"
 OBJS=""
+PIDS=""
 mkdir -p build
 for s in $SRCS; do
   o=build/${s%.hip}.o
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ od_common.h -nt "$o" ] || [ od_tiles.h -nt "$o" ] || [ ../../include/osu_dreamer_hip.h -nt "$o" ]; then
+  stale=0
+  [ -f "$o" ] || stale=1
+  for dep in "$s" od_common.h od_tiles.h od_api_internal.h ../../include/osu_dreamer_hip.h build.sh; do
+    [ "$dep" -nt "$o" ] && stale=1
+  done
+  if [ $stale = 1 ]; then
+    rm -f "$o"                  # a failed compile must not leave an old object for the link step
     extra=""
     # attn.hip has no NaN/Inf by construction (finite -1e30 mask): lets hipcc drop the canonicalising v_max
     [ "$s" = "attn.hip" ] && extra="-ffinite-math-only"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c "$s" -o "$o" ${OD_HIPCC_FLAGS} &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
+for p in $PIDS; do wait $p || { echo "hipcc failed" >&2; exit 1; }; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $OUT
 echo "built $OUT"

@@ -95,6 +95,7 @@ extern "C" const char* od_error_string(int code) {
         case OD_ERR_ARG: return "invalid argument";
         case OD_ERR_ALIGN: return "leading dimension / size not aligned to the kernel's vector width";
         case OD_ERR_UNSUPPORTED: return "shape outside the compiled kernel set";
+        case OD_ERR_COMM: return "RCCL call failed (or librccl could not be bound)";
         default: break;
     }
 #if !defined(OD_EMU)

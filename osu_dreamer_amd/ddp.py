@@ -1,5 +1,5 @@
-"""Data-parallel gradient exchange: one process per GPU, `torch.distributed` (backend "nccl"
-is RCCL on ROCm) over xGMI.
+"""Data-parallel gradient exchange: one process per GPU, RCCL over xGMI through the C ABI
+(`od_allreduce_grads` / `od_broadcast_f32`, csrc/comm.hip).
 
 The reference is single-device (models/diffusion/model.yml:11); the only exchange a
 data-parallel denoiser needs is the mean of the 46.9 M fp32 parameter gradients (187.5 MB).
@@ -9,13 +9,63 @@ layer 7 … layer 0 (23.4 MB each), head — each all-reduced on a side stream t
 backward kernels that write it have been enqueued, overlapping the remaining backward.  The
 EMA copy is never reduced.  Gradient clipping happens after the exchange, so the norm is
 identical on every rank without a second collective.
+
+`torch.distributed` is used for rendezvous only: it ships the 128-byte RCCL unique id from rank 0 to the
+other ranks (and provides the host-side barrier / step-agreement of the trainer shell).  When the bound
+kernel library is the CPU emulator build (the test-suite's world-size-2 gloo run) there is no RCCL and the
+same buckets go through `torch.distributed.all_reduce` on the gloo group instead.
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
+
+from . import _lib
+
+UNIQUE_ID_BYTES = 128
+
+
+def torch_rccl_path() -> Optional[str]:
+    """PyTorch's own librccl.so, so that this process holds ONE RCCL instance."""
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
+
+
+class RcclComm:
+    """A communicator created through the C ABI (ncclCommInitRank on the current device)."""
+
+    def __init__(self, device: torch.device, process_group=None):
+        L = _lib.lib()
+        L.od_comm_load((os.environ.get("OD_RCCL_LIB") or torch_rccl_path() or "").encode())
+        self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        ident = (ctypes.c_ubyte * UNIQUE_ID_BYTES)()
+        if self.rank == 0:
+            L.od_comm_unique_id(ident, UNIQUE_ID_BYTES)
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0, group=process_group)      # rendezvous only: 128 bytes of host memory
+        ident = (ctypes.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(box[0])
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            L.od_comm_init(ctypes.byref(self._comm), self.world, self.rank, ident, UNIQUE_ID_BYTES)
+        self.version = int(L.cdll.od_comm_version())
+
+    def allreduce_mean_(self, t: torch.Tensor):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        _lib.lib().od_allreduce_grads(self._comm, t.data_ptr(), t.numel(), 1, torch.cuda.current_stream(t.device).cuda_stream)
+
+    def broadcast_(self, t: torch.Tensor, root: int = 0):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        _lib.lib().od_broadcast_f32(self._comm, t.data_ptr(), t.numel(), root, torch.cuda.current_stream(t.device).cuda_stream)
+
+    def close(self):
+        if self._comm:
+            torch.cuda.synchronize()
+            _lib.lib().od_comm_destroy(self._comm)
+            self._comm = ctypes.c_void_p()
 
 
 class GradBucketReducer:
@@ -30,17 +80,44 @@ class GradBucketReducer:
         self._handles: List = []
         self._comm_stream: Optional[torch.cuda.Stream] = None
         self._done = set()
-        backend = dist.get_backend(process_group)
-        self._avg = backend == "nccl"
+        dev = model.arena.data.device
+        self.comm: Optional[RcclComm] = RcclComm(dev, process_group) if dev.type == "cuda" else None
         model._reducer = self
+
+    # ---- start-up / resume: every rank continues from rank `src`'s state ------------------------------
+    def _bcast(self, t: torch.Tensor, src: int):
+        if self.comm is not None:
+            self.comm.broadcast_(t, src)
+        else:
+            dist.broadcast(t, src=src, group=self.pg)
 
     def broadcast_parameters(self, src: int = 0):
         """Every rank starts from rank `src`'s weights (what DDP does at construction)."""
-        dist.broadcast(self.model.arena.data, src=src, group=self.pg)
+        self._bcast(self.model.arena.data, src)
 
-    def _reduce(self, t: torch.Tensor):
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        return dist.all_reduce(t, op=op, group=self.pg, async_op=True)
+    def broadcast_state(self, optimizer=None, ema=None, src: int = 0):
+        """Parameters, AdamW moments / step count and the EMA copy: everything a step reads besides the batch.
+        Identical seeding is not relied on (a resumed rank 0 and fresh peers would otherwise diverge silently)."""
+        self.broadcast_parameters(src)
+        if optimizer is not None:
+            self._bcast(optimizer.exp_avg, src)
+            self._bcast(optimizer.exp_avg_sq, src)
+            meta = [optimizer.step_count]
+            dist.broadcast_object_list(meta, src=src, group=self.pg)
+            optimizer.step_count = int(meta[0])
+        if ema is not None:
+            self._bcast(ema.module.arena.data, src)
+            meta = [ema.count]
+            dist.broadcast_object_list(meta, src=src, group=self.pg)
+            ema.count = int(meta[0])
+            ema.n_averaged.fill_(ema.count)
+
+    # ---- the per-step exchange -----------------------------------------------------------------------
+    def _reduce(self, g: torch.Tensor):
+        if self.comm is not None:
+            self.comm.allreduce_mean_(g)          # enqueued on the current stream (the side stream when overlapping)
+            return None
+        return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def segment_done(self, name: str):
         """Called by DenoiserEngine.backward when all kernels writing `name`'s gradients are enqueued."""
@@ -64,10 +141,34 @@ class GradBucketReducer:
             if name not in self._done:
                 self.segment_done(name)
         for h, g in self._handles:
-            h.wait()
-            if not self._avg:
+            if h is not None:                   # gloo (emulator build): host-side handle, sum -> mean
+                h.wait()
                 g.div_(self.world)
         if self._comm_stream is not None:
             torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
         self._handles.clear()
         self._done.clear()
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+
+
+class StepAgreement:
+    """Keeps the ranks of a data-parallel epoch in lock step when their shards differ in length: before every
+    optimizer step the ranks agree (MIN over a host-side flag) whether ALL of them still have a batch; the epoch
+    ends for everyone as soon as one rank runs dry, so no rank is left waiting in an all-reduce."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self._group = None
+        if world > 1:
+            # a host-side (gloo) group: the agreement must not synchronise the device stream
+            self._group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+
+    def all_have(self, have_batch: bool) -> bool:
+        if self.world <= 1:
+            return have_batch
+        flag = torch.tensor([1 if have_batch else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
+        return bool(flag.item())

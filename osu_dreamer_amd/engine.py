@@ -72,6 +72,9 @@ class DenoiserEngine:
         self._plan_key = None
         self.ws: Optional[Workspace] = None
         self._rowmap = None
+        # bumped whenever the workspace or the packed weights are re-allocated: anything that captured their addresses
+        # (the sampler's hipGraph) is stale from then on
+        self.generation = 0
 
     # ------------------------------------------------------------------ parameters
     def P(self, name: str) -> torch.Tensor:
@@ -94,6 +97,7 @@ class DenoiserEngine:
         if self._packed_key != key:
             self._packed = {}
             self._packed_key = key
+            self.generation += 1
             Hf, Hp = self.Hf, self.Hp
             rm = [-1] * (2 * Hp)
             for j in range(Hf):
@@ -134,6 +138,7 @@ class DenoiserEngine:
         if key != self._plan_key:
             self.ws = Workspace(dev)
             self._plan_key = key
+            self.generation += 1
             tab = self.ws.get("rope", (L, self.hd // 2, 2), torch.float32)
             ops.rope_table(tab, L, self.hd)
         self.B, self.L, self.Ba, self.dtype, self.train, self.x3 = B, L, Ba, dtype, train, x3
@@ -244,6 +249,12 @@ class DenoiserEngine:
         ops.uhead_fwd(xt, self._uhead_w(), fsum, self.U)
         ops.uhead_tail(fsum, self.ws.t["umod"], self.P("u_out.weight"), self.P("u_out.bias"), u, L, self.model.u_scale)
 
+    def attn_bwd_launch(self, qk, qkv, y, dy, lse, delta, dqk, dqkv):
+        """The attention backward of one layer exactly as `backward` launches it (also what bench.py times alone)."""
+        dh = self.dh
+        ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
+                           dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, 1.0 / math.sqrt(self.hd), q_prescaled=True)
+
     def _uhead_w(self, grads=False):
         f = self.G if grads else self.P
         return [f(f"u_head.{j}.{s}") for j in (0, 1, 3, 4) for s in ("weight", "bias")]
@@ -309,9 +320,7 @@ class DenoiserEngine:
             ops.gemm_tn(dbr, t[f"y.{i}"], self.G(p + "attn.out_proj.weight"), dbias=self.G(p + "attn.out_proj.bias"))
             ops.gemm_nt(dbr, self.W(p + "attn.out_proj", T=True), None, dy)
             qk, qkv = t[f"qk.{i}"], t[f"qkv.{i}"]
-            ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], t[f"y.{i}"], dy, t[f"lse.{i}"], delta,
-                               dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:], B, self.H, L, self.hd, 1.0 / math.sqrt(self.hd),
-                               q_prescaled=True)
+            self.attn_bwd_launch(qk, qkv, t[f"y.{i}"], dy, t[f"lse.{i}"], delta, dqk, dqkv)
             ops.qk_norm_rope_bwd(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, dqk, dqkv,
                                  self.G(p + "attn.q_norm.weight"), self.G(p + "attn.k_norm.weight"), B, L, self.H,
                                  self.hd, FP32_EPS, q_scale=self.q_scale)

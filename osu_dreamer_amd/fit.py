@@ -29,7 +29,7 @@ import numpy as np
 import torch
 import yaml
 
-from . import _lib
+from . import _lib, launch
 from .data import LatentDataModule
 from .lr_schedule import LRScheduleArgs
 from .model import BackboneArgs, DiffusionModelArgs
@@ -70,7 +70,14 @@ class Trainer:
         self.enable_checkpointing = enable_checkpointing
         self.global_step, self.epoch = 0, 0
         self.best_val = float("inf")
+        # `devices: N` = N ranks, one per GPU (model.yml:11).  The ranks are started by `fit_denoiser` / the CLI
+        # (launch.spawn_ranks_if_needed) before anything touches the GPU; inside a rank WORLD_SIZE must agree.
+        self.devices = int(devices) if not isinstance(devices, (list, tuple)) else len(devices)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.devices > 1 and self.world != self.devices:
+            raise RuntimeError(f"trainer.devices={self.devices} but WORLD_SIZE={self.world}: start the run through "
+                               "`python -m osu_dreamer_amd fit-denoiser` / fit_denoiser() (they spawn the ranks), or under "
+                               f"`torchrun --nproc-per-node {self.devices}`")
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.history = []
@@ -135,17 +142,26 @@ class Trainer:
             sched.load_state_dict(ck["lr_schedulers"][0])
             self.global_step, self.epoch = ck["global_step"], ck["epoch"]
             self.best_val = ck.get("best_val", float("inf"))
+        from .ddp import StepAgreement
         if self.world > 1:
             from .ddp import GradBucketReducer
             reducer = GradBucketReducer(module.diffusion)
-            reducer.broadcast_parameters(0)
+            reducer.broadcast_state(opt, module.diffusion_ema, src=0)     # weights, AdamW moments, EMA: rank 0's
+        agree = StepAgreement(self.world)
         log_path = os.path.join(self.root, "metrics.jsonl")
         if self.rank == 0:
             os.makedirs(self.root, exist_ok=True)
         t_last = time.time()
         done = False
         while not done:
-            for batch_idx, batch in enumerate(datamodule.train_dataloader()):
+            it = iter(datamodule.train_dataloader())
+            batch_idx = -1
+            while True:
+                batch = next(it, None)
+                # uneven shards: the epoch ends for every rank as soon as one rank has no batch left
+                if not agree.all_have(batch is not None):
+                    break
+                batch_idx += 1
                 batch = self._to(batch, device)
                 opt.zero_grad()
                 with self._autocast(device):
@@ -209,6 +225,11 @@ def fit_denoiser(config: str = DEFAULT_CONFIG, ckpt_path: Optional[str] = None, 
         cfg.setdefault(sec, {})[key] = v
     if cfg.get("seed_everything") not in (None, False):
         seed_everything(cfg["seed_everything"])
+    devices = cfg.get("trainer", {}).get("devices", 1)
+    devices = len(devices) if isinstance(devices, (list, tuple)) else int(devices)
+    if devices > 1 and launch.world_from_env() is None:
+        raise RuntimeError("fit_denoiser(devices > 1) must run inside a rank: use `python -m osu_dreamer_amd fit-denoiser` "
+                           "(it starts the ranks) or torchrun")
     module, trainer = build_from_config(cfg)
     data = LatentDataModule(**cfg["data"], rank=trainer.rank, world_size=trainer.world)
     trainer.fit(module, data, ckpt_path=ckpt_path)
@@ -223,6 +244,14 @@ def main(argv=None):
     f.add_argument("--ckpt-path", default=None)
     a = ap.parse_args(argv)
     if a.cmd == "fit-denoiser":
+        with open(a.config) as fh:
+            devices = (yaml.safe_load(fh).get("trainer") or {}).get("devices", 1)
+        devices = len(devices) if isinstance(devices, (list, tuple)) else int(devices)
+        # trainer.devices N > 1: this process only starts the N ranks (children; nothing here has touched the GPU)
+        rc = launch.spawn_ranks_if_needed(devices, ["fit-denoiser", "-c", a.config] + (["--ckpt-path", a.ckpt_path] if a.ckpt_path else []),
+                                          module="osu_dreamer_amd")
+        if rc is not None:
+            raise SystemExit(rc)
         fit_denoiser(a.config, a.ckpt_path)
 
 

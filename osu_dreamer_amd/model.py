@@ -194,7 +194,9 @@ class DiffusionModel(nn.Module):
                 if part not in mod._modules:
                     mod.add_module(part, _Node())
                 mod = mod._modules[part]
-            mod._parameters[parts[-1]] = nn.Parameter(self.arena.view(name))
+            old = mod._parameters.get(parts[-1])
+            # .to()/.cuda() re-create the views: keep requires_grad (EMA / inference copies are frozen)
+            mod._parameters[parts[-1]] = nn.Parameter(self.arena.view(name), requires_grad=True if old is None else old.requires_grad)
 
     def _apply(self, fn, recurse=True):
         """`.to()/.cuda()/.float()` move the arena as a whole and re-create the views."""
@@ -299,10 +301,12 @@ class DiffusionModel(nn.Module):
             except ImportError:
                 pass
         if self.use_graph and dev.type == "cuda" and num_steps > 1:
-            # the captured step only references plan-owned buffers (x, u, v, eta, workspace, packed weights),
-            # so one instantiated graph serves every later call with the same plan
+            # the captured step only references plan-owned buffers (x, u, v, eta, workspace, packed weights), so one
+            # instantiated graph serves later calls — as long as those buffers are the SAME allocations: a forward or
+            # train step with another shape in between re-plans (new workspace / packed weights), which bumps
+            # `generation` and retires the graph even when the plan key comes back equal
             from .graph import CapturedLoop
-            key = (eng._plan_key, eng._packed_key)
+            key = (eng._plan_key, eng._packed_key, eng.generation)
             if self._graph is None or self._graph[0] != key:
                 if self._graph is not None:
                     self._graph[1].close()

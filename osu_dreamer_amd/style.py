@@ -78,6 +78,7 @@ class StyleModel(nn.Module):
             self.blocks.add_module(str(i), blk)
         self.requires_grad_(False)
         self._buf: Dict[str, torch.Tensor] = {}
+        self._buf_gen = 0          # bumped on every (re)allocation: a captured graph holding old addresses is stale
 
     # ------------------------------------------------------------------
     def _b(self, name, shape, like):
@@ -85,6 +86,7 @@ class StyleModel(nn.Module):
         if t is None or tuple(t.shape) != tuple(shape) or t.device != like.device:
             t = torch.zeros(shape, dtype=torch.float32, device=like.device)
             self._buf[name] = t
+            self._buf_gen += 1
         return t
 
     def _w(self):
@@ -157,7 +159,7 @@ class StyleModel(nn.Module):
 
         if self.use_graph and dev.type == "cuda" and num_steps > 1:
             from .graph import CapturedLoop
-            key = (B, dev, tuple(t.data_ptr() for t in W.values()))
+            key = (B, dev, self._buf_gen, tuple(t.data_ptr() for t in W.values()))
             if getattr(self, "_graph", None) is None or self._graph[0] != key:
                 if getattr(self, "_graph", None) is not None:
                     self._graph[1].close()

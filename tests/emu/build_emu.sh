@@ -6,13 +6,16 @@ CS=../../osu_dreamer_amd/csrc
 OUT=libod_emu.so
 mkdir -p build
 OBJS=""
-for s in gemm rowops misc heads optim attn style latent; do
+PIDS=""
+for s in gemm rowops misc heads optim attn style latent comm; do
   o=build/$s.o
-  if [ ! -f "$o" ] || [ "$CS/$s.hip" -nt "$o" ] || [ "$CS/od_common.h" -nt "$o" ] || [ "$CS/od_tiles.h" -nt "$o" ] || [ emu_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$CS/$s.hip" -nt "$o" ] || [ "$CS/od_common.h" -nt "$o" ] || [ "$CS/od_tiles.h" -nt "$o" ] || [ "$CS/od_api_internal.h" -nt "$o" ] || [ ../../include/osu_dreamer_hip.h -nt "$o" ] || [ emu_hip.h -nt "$o" ]; then
+    rm -f "$o"
     /opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fPIC -DOD_EMU -DOD_GEMM_BIG_MIN_M=256 -DOD_DW_SMALL_THREADS=10 -DOD_GEMM_SMALL_TILES=6 -I. -I$CS -Wno-unused-value -c $CS/$s.hip -o $o &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
-wait
+for p in $PIDS; do wait $p || { echo "emulator build failed" >&2; exit 1; }; done
 /opt/rocm/lib/llvm/bin/clang++ -shared -fPIC $OBJS -o $OUT
 echo "built $OUT"
