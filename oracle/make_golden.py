@@ -407,12 +407,158 @@ def gen_ldm(out_dir, name, ld, sd_, dd, B, L, num_steps, seed):
     print(name, "chart", tuple(chart.shape), float(chart.abs().mean()))
 
 
+
+def _grad_store(fx, prefix, grads, full):
+    for k, g in grads.items():
+        if full:
+            fx[f"{prefix}." + k] = g
+        else:
+            fx[f"{prefix}norm." + k] = g.norm()
+            fx[f"{prefix}sub." + k] = g.flatten()[::max(1, g.numel() // 64)][:64]
+
+
+def gen_train_bf16(out_dir, name, d: O.Dims, B, L, seed, store_full):
+    """The reference's training loss and gradients under `precision: bf16-mixed` (model.yml:12), i.e.
+    DiffusionTrainer.forward + backward inside torch.autocast(bfloat16), next to the same quantities in fp32
+    on the same weights / batch / noise (same seeds as the fp32 fixture of that config).  The pair anchors the
+    tolerance of the HIP bf16 training step: its error against fp32 must stay within a small multiple of the
+    reference's own bf16-vs-fp32 error."""
+    import osu_dreamer.models.diffusion.train as train_mod
+    P = O.init_params(d, seed=seed)
+    data = O.synthetic_batch(d, B, L, seed=seed + 1)
+    fx = {"dims": np.array(list(d.to_dict().values())), "B": B, "L": L, "seed": seed}
+    u01 = torch.special.ndtr(torch.logit(data["t"].double())).float()
+    u_eff = (torch.zeros(B) + u01 * B) / B
+    fx["t_used"] = torch.special.ndtri(u_eff.clamp(1e-6, 1 - 1e-6)).sigmoid()
+    for tag, ctx in (("f32", torch.autocast("cpu", enabled=False)), ("bf16", torch.autocast("cpu", dtype=torch.bfloat16))):
+        tr = _ref_trainer(d, P)
+        with _FixedNoise(train_mod, u01, data["x0"]):
+            tr.zero_grad()
+            with ctx:
+                loss, logs = tr(tr.diffusion, data["h"], data["z"], data["s"], torch.zeros(B, 5))
+        loss.backward()
+        grads = {k: (p.grad.detach().float().clone() if p.grad is not None else torch.zeros_like(p))
+                 for k, p in tr.diffusion.named_parameters()}
+        fx[f"{tag}.loss"] = loss.detach().float()
+        for k, v in logs.items():
+            fx[f"{tag}.log_{k}"] = v.float()
+        fx[f"{tag}.grad_norm"] = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+        _grad_store(fx, f"{tag}.grad", grads, store_full)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
+    print(name, "loss f32", float(fx["f32.loss"]), "bf16", float(fx["bf16.loss"]),
+          "gnorm f32", float(fx["f32.grad_norm"]), "bf16", float(fx["bf16.grad_norm"]))
+
+
+def gen_validation(out_dir, name, d: O.Dims, val_batches, l, seed):
+    """The reference's `validation_step` (train.py:128-139): one full map (1, C, l) cut into `val_batches` segments,
+    loss under no_grad with the EMA weights.  The EMA copy is given DIFFERENT weights from the live model so that a
+    step evaluating the wrong one cannot match.  `l` is deliberately not a multiple of `val_batches`."""
+    import osu_dreamer.models.diffusion.train as train_mod
+    P, Pe = O.init_params(d, seed=seed), O.init_params(d, seed=seed + 7)
+    g = torch.Generator().manual_seed(seed + 1)
+    h = torch.randn(1, d.a_dim, l, generator=g)
+    z = torch.randn(1, d.emb_dim, l, generator=g)
+    z = z * z.pow(2).mean(1, keepdim=True).add(1e-6).rsqrt()
+    s = torch.randn(1, d.style_dim, generator=g)
+    labels = torch.rand(1, 5, generator=g) * 10
+    seg = l // val_batches
+    t = torch.rand(val_batches, generator=g) * 0.9 + 0.05
+    x0 = torch.randn(val_batches, d.emb_dim, seg, generator=g)
+    u01 = torch.special.ndtr(torch.logit(t.double())).float()
+    u_eff = (torch.zeros(val_batches) + u01 * val_batches) / val_batches
+    tr = _ref_trainer(d, P, val_batches=val_batches)
+    tr.diffusion_ema.module.load_state_dict(Pe)
+    logged = {}
+    tr.log_dict = lambda dct, *a, **k: logged.update({kk: vv.detach().clone() for kk, vv in dct.items()})
+    with _FixedNoise(train_mod, u01, x0):
+        tr.validation_step((h, z, s, labels), 0)
+    fx = {"dims": np.array(list(d.to_dict().values())), "seed": seed, "val_batches": val_batches, "l": l,
+          "h": h, "z": z, "s": s, "labels": labels, "x0": x0,
+          "t_used": torch.special.ndtri(u_eff.clamp(1e-6, 1 - 1e-6)).sigmoid()}
+    for k, v in logged.items():
+        fx["log." + k.replace("/", "_")] = v
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
+    print(name, {k: float(v) for k, v in logged.items()})
+
+
+def gen_rope_long(out_dir, N=32768, D=64, seed=900):
+    """`rope()` (common/attn.py:12-29) at BASELINE configs[4]'s length: positions up to 32767, where one ulp of a
+    high inverse frequency is already 2e-3 rad.  Rows are sub-sampled (input and output stored for the same rows)."""
+    from osu_dreamer.common.attn import rope, _rope_cache
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.cat([torch.arange(0, 8), torch.tensor([63, 64, 1000, 1115, 4095, 4096, 8191, 8192, 12345, 16384, 20000,
+                                                       30000, 32766, 32767])])
+    x = torch.zeros(1, 2, N, D)
+    x[:, :, pos] = torch.randn(1, 2, len(pos), D, generator=g)
+    with torch.no_grad():
+        y = rope(x)
+    freqs = _rope_cache[(D, x.device)][:N]
+    np.savez_compressed(os.path.join(out_dir, "rope_long.npz"),
+                        **np_dict(N=N, D=D, pos=pos, x=x[:, :, pos], y=y[:, :, pos], angle=freqs[pos],
+                                  inv_freq=10000 ** (torch.arange(0, D, 2).float() / -D)))
+    print("rope_long", tuple(y[:, :, pos].shape))
+
+
+def gen_feeder(out_dir, seed=1000):
+    """The sample stream of the reference's LatentDataset (data/modules/latent.py:83-149) on a synthetic dataset written
+    by OUR writer (osu_dreamer_amd.data.write_synthetic_dataset: deterministic numpy, re-created by the test): window
+    offsets, per-map permutation, max_per_map cut, shuffle buffer, and the train/val mapset split of
+    data/modules/beatmap.py:33-71.  world_size 1, no workers, torch.manual_seed(seed) before each iteration."""
+    import tempfile
+    from pathlib import Path
+    from osu_dreamer.data.modules.latent import LatentDataset as RefDataset
+    from osu_dreamer.data.modules.beatmap import hold_out_mapsets as ref_split
+    from osu_dreamer_amd.data import write_synthetic_dataset
+    frames = [200, 96, 333, 64, 150, 47, 260]
+    fx = {"seed": seed, "frames": np.array(frames), "a_dim": 4, "emb_dim": 3, "style_dim": 2}
+    with tempfile.TemporaryDirectory() as tmp:
+        write_synthetic_dataset(tmp, n_maps=len(frames), frames=frames, a_dim=4, emb_dim=3, style_dim=2, seed=seed)
+        root = Path(tmp)
+        mapsets = sorted(root.iterdir())
+        full = {m.name: (np.load(m / "h.npy"), np.load(m / "0.latent.npz")["z"]) for m in mapsets}
+        # the split: the reference walks data_dir.iterdir() (unsorted); record it by mapset name
+        tr_sets, val_sets = ref_split(root, "*.latent.npz", 3, .3)
+        fx["split_listing"] = np.array([m.name for m in root.iterdir()])
+        fx["split_train"] = np.array([m.name for m in tr_sets])
+        fx["split_val"] = np.array([m.name for m in val_sets])
+        for tag, kw in (("plain", dict(seq_len=48, shuffle_buffer_size=1, max_per_map=-1)),
+                        ("shuffled", dict(seq_len=32, shuffle_buffer_size=4, max_per_map=3)),
+                        ("fullmaps", dict(seq_len=None))):
+            torch.manual_seed(seed)
+            ds = RefDataset(mapsets, **kw)
+            recs, sums = [], []
+            for smp in ds:
+                name = next(n for n, (hh, zz) in full.items() if np.allclose(np.load(root / n / "0.latent.npz")["s"], smp.s.numpy()))
+                hh, zz = full[name]
+                l = smp.z.shape[-1]
+                starts = [i for i in range(zz.shape[-1] - l + 1) if np.array_equal(zz[:, i:i + l], smp.z.numpy())]
+                assert len(starts) == 1 and np.array_equal(hh[:, starts[0]:starts[0] + l], smp.h.numpy())
+                recs.append((int(name), starts[0], l))
+                sums.append(float(smp.h.double().sum() + smp.z.double().sum()))
+            fx[f"{tag}.stream"] = np.array(recs)
+            fx[f"{tag}.sums"] = np.array(sums)
+    np.savez_compressed(os.path.join(out_dir, "feeder_stream.npz"), **fx)
+    print("feeder", {k: v.shape for k, v in fx.items() if hasattr(v, "shape") and k.endswith("stream")})
+
+
+def gen_round2(out_dir):
+    gen_rope_long(out_dir)
+    gen_feeder(out_dir)
+    gen_train_bf16(out_dir, "train_bf16_tiny_b3_l40", O.TINY, B=3, L=40, seed=100, store_full=True)
+    gen_train_bf16(out_dir, "train_bf16_full_d2_b2_l96", O.Dims(depth=2), B=2, L=96, seed=300, store_full=False)
+    gen_validation(out_dir, "val_tiny", O.TINY, val_batches=3, l=50, seed=1100)
+    gen_validation(out_dir, "val_full_d2", O.Dims(depth=2), val_batches=8, l=8 * 24 + 5, seed=1200)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     _install_shims()
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if os.environ.get("GOLDEN_ONLY") == "round2":
+        gen_round2(out_dir)
+        return
     gen_lr(out_dir)
     gen_ops(out_dir)
     from oracle import style_oracle as SO
@@ -445,6 +591,7 @@ def main():
     # full default config (46.9 M params) at a short length
     gen_model(out_dir, "full_d8_b2_l64", O.FULL, B=2, L=64, seed=400, store_weights=False,
               num_steps=4)
+    gen_round2(out_dir)
 
 
 if __name__ == "__main__":

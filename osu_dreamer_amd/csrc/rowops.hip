@@ -719,8 +719,12 @@ __global__ void rope_table_kernel(float* __restrict__ table, int L, int hd) {
     const int half = hd / 2;
     if (i >= (long)L * half) return;
     const int l = (int)(i / half), j = (int)(i % half);
-    // inv_freq = 10000^(-2j/hd) computed like the reference: float pow, then float product l*inv_freq
-    const float inv_freq = powf(10000.0f, -(float)(2 * j) / (float)hd);
+    // inv_freq = 10000^(e), e = (float)(2j) / (float)(-hd) as the reference forms it (attn.py:19), then the fp32 product
+    // l * inv_freq (attn.py:21).  The power goes through double and is rounded once: a fast fp32 pow that is 1 ulp off at a
+    // HIGH frequency would be 2e-3 rad at position 32768; this way the table never depends on the device's powf (torch's
+    // own fp32 pow differs from the correctly rounded value at two LOW frequencies only: <= 8e-6 rad at 32768).
+    const float e = (float)(2 * j) / (float)(-hd);
+    const float inv_freq = (float)pow(10000.0, (double)e);
     const float ang = (float)l * inv_freq;
     table[2 * i] = cosf(ang);
     table[2 * i + 1] = sinf(ang);

@@ -35,13 +35,13 @@ def load_latents(latent_file: Path) -> LatentBatch:
     return LatentBatch(h, z, s, labels)
 
 
-def hold_out_mapsets(data_dir: Path, pattern: str, max_val_count: int, max_val_frac: float) -> Tuple[List[Path], List[Path]]:
-    """Whole mapsets (directories) are held out so train/val never share audio."""
-    if not data_dir.exists():
-        raise ValueError(f"data dir `{data_dir}` does not exist, generate dataset first")
-    full = sum(1 for _ in data_dir.rglob(pattern))
+def split_mapsets(mapsets: List[Path], counts: List[int], max_val_count: int, max_val_frac: float) -> Tuple[List[Path], List[Path]]:
+    """The hold-out rule of data/modules/beatmap.py:38-71 on an ORDERED list of mapsets with their map counts: walk the
+    list, a mapset goes to validation while the validation set stays within min(max_val_count, int(total * max_val_frac))
+    maps, otherwise to training."""
+    full = sum(counts)
     if full == 0:
-        raise ValueError(f"data dir `{data_dir}` is empty, generate dataset first")
+        raise ValueError("data dir is empty, generate dataset first")
     if max_val_count <= 0:
         raise ValueError(f"invalid {max_val_count=}")
     if not (0 < max_val_frac < 1):
@@ -50,14 +50,30 @@ def hold_out_mapsets(data_dir: Path, pattern: str, max_val_count: int, max_val_f
     if not (0 < cap < full):
         raise ValueError(f"invalid max_val_size={cap} given full_size={full} {max_val_count=} {max_val_frac=}")
     train, val, nval = [], [], 0
-    for mapset in sorted(data_dir.iterdir()):
-        n = sum(1 for _ in mapset.glob(pattern))
+    for mapset, n in zip(mapsets, counts):
         if nval + n > cap:
             train.append(mapset)
         else:
             val.append(mapset)
             nval += n
     return train, val
+
+
+def hold_out_mapsets(data_dir: Path, pattern: str, max_val_count: int, max_val_frac: float) -> Tuple[List[Path], List[Path]]:
+    """Whole mapsets (directories) are held out so train/val never share audio.  The reference walks
+    `data_dir.iterdir()` in file-system order, so its split differs from machine to machine; here the listing is sorted,
+    which every rank of a data-parallel run needs anyway (all ranks must hold out the SAME mapsets)."""
+    if not data_dir.exists():
+        raise ValueError(f"data dir `{data_dir}` does not exist, generate dataset first")
+    mapsets = sorted(data_dir.iterdir())
+    counts = [sum(1 for _ in m.glob(pattern)) for m in mapsets] if mapsets else []
+    extra = sum(1 for _ in data_dir.rglob(pattern)) - sum(counts)      # maps nested deeper count towards the total (rglob)
+    if sum(counts) + extra == 0:
+        raise ValueError(f"data dir `{data_dir}` is empty, generate dataset first")
+    if extra:
+        mapsets, counts = mapsets + [None], counts + [extra]
+    train, val = split_mapsets(mapsets, counts, max_val_count, max_val_frac)
+    return [m for m in train if m is not None], [m for m in val if m is not None]
 
 
 class LatentDataset(IterableDataset):
@@ -131,15 +147,17 @@ class LatentDataModule:
                           persistent_workers=self.num_workers > 0)
 
 
-def write_synthetic_dataset(data_path: str, n_maps: int = 8, frames: int = 4096, a_dim: int = 128, emb_dim: int = 6,
+def write_synthetic_dataset(data_path: str, n_maps: int = 8, frames=4096, a_dim: int = 128, emb_dim: int = 6,
                             style_dim: int = 32, seed: int = 0):
     """`n_maps` mapset dirs each with h.npy (A, frames) and 0.latent.npz {z (E, frames), s (S,), labels (5,)}:
-    h ~ N(0,1), z per-frame RMS-normalised, s RMS-normalised."""
+    h ~ N(0,1), z per-frame RMS-normalised, s RMS-normalised.  `frames` may be a list (one length per map)."""
     rng = np.random.default_rng(seed)
     root = Path(data_path)
+    lengths = list(frames) if isinstance(frames, (list, tuple)) else [frames] * n_maps
     for i in range(n_maps):
         d = root / f"{i:04d}"
         d.mkdir(parents=True, exist_ok=True)
+        frames = lengths[i]
         z = rng.standard_normal((emb_dim, frames)).astype(np.float32)
         z /= np.sqrt((z * z).mean(0, keepdims=True) + 1e-6)
         s = rng.standard_normal(style_dim).astype(np.float32)

@@ -143,7 +143,8 @@ class DiffusionTrainer(_Base):
     def on_train_batch_end(self, *args, **kwargs):
         self.diffusion_ema.update_parameters(self.diffusion)
 
-    def validation_step(self, batch, batch_idx, *args, **kwargs):
+    def validation_step(self, batch, batch_idx, *args, t=None, x0=None, **kwargs):
+        """train.py:128-139.  `t` / `x0` (keyword-only, not in the reference's signature) pin the noise for parity tests."""
         h, z, s, l = batch
         with torch.no_grad():
             vb = self.val_batches
@@ -154,7 +155,7 @@ class DiffusionTrainer(_Base):
             z = z[..., :bl].reshape(z.size(1), vb, seg).permute(1, 0, 2).contiguous()
             s = s.expand(vb, -1).contiguous()
             l = l.expand(vb, -1).contiguous()
-            _, log_dict = self(self.diffusion_ema.module, h, z, s, l)
+            _, log_dict = self(self.diffusion_ema.module, h, z, s, l, t=t, x0=x0)
         self._log({f"val/{k}": v for k, v in log_dict.items()})
         return log_dict
 

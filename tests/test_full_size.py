@@ -6,8 +6,10 @@ oracle cannot run L=8192 in test time):
     backward: dV linear in dO, sum_keys dP-consistency (dQ, dK, dV vs torch autograd on a sub-problem
     that shares the same keys).
   * GEMMs at the bench shapes against torch.matmul (fp32 accumulate) — a plain PyTorch reference.
-  * whole training step at L=8192 (fp32 compute, batch 2, full 46.9 M-param model): central-difference
-    directional derivative of the loss vs <grad, direction>.
+  * whole training step at L=8192 (fp32 compute, batch 4 = 32768 frames, so the large-M 256x256 GEMM kernels are the ones
+    running; full 46.9 M-param model): central-difference directional derivative of the loss vs <grad, direction>.
+  * whole bf16 training step (the bench's compute type) against the fp32 step on the same batch and noise, at
+    configs[1]'s length (batch 4 x 8192) and configs[4]'s (batch 1 x 32768): loss, gradient norm, per-segment gradients.
   * sampler at configs[3] size: hipGraph replay == eager launches, bit for bit.
 """
 import math
@@ -121,7 +123,7 @@ def test_train_step_directional_derivative_L8192(dev):
     import bench
     tr = bench.make_trainer(dev, seed=11)
     model = tr.diffusion
-    B, L = 2, 8192
+    B, L = 4, 8192                 # M = 32768 >= OD_GEMM_BIG_MIN_M: the 256 x 256 NT / TN kernels carry the GEMMs
     h, z, s, _ = bench.synthetic_batch(B, L, dev, seed=12)
     g = torch.Generator(device=dev).manual_seed(13)
     t = torch.rand(B, device=dev, generator=g) * 0.8 + 0.1
@@ -148,6 +150,45 @@ def test_train_step_directional_derivative_L8192(dev):
     fd = (vals[0] - vals[1]) / (2 * eps)
     an = float((grad.double() * d.double()).sum())
     assert abs(fd - an) <= 2e-2 * abs(an), (fd, an, eps)
+
+
+@pytest.mark.parametrize("B,L", [(4, 8192), (1, 32768)])      # configs[1]'s length at M = 32768; configs[4]'s length
+def test_bf16_step_agrees_with_fp32_step(dev, B, L):
+    """The bench's bf16 training step end to end (256 x 256 GEMM kernels, bf16 flash attention fwd + bwd, row kernels,
+    loss) against the SAME step in fp32 compute — itself validated by the directional-derivative test above and, at small
+    sizes, against the reference's gradients.  Bounds follow the reference's own bf16-autocast error on the depth-2 fixture
+    (tests/golden/train_bf16_full_d2_b2_l96.npz: loss 7e-4, per-tensor gradients 1e-2 median), allowing for depth 8."""
+    import bench
+    tr = bench.make_trainer(dev, seed=21)
+    model = tr.diffusion
+    h, z, s, _ = bench.synthetic_batch(B, L, dev, seed=22)
+    g = torch.Generator(device=dev).manual_seed(23)
+    t = torch.rand(B, device=dev, generator=g) * 0.8 + 0.1
+    x0 = torch.randn(B, 6, L, device=dev, generator=g)
+    opt = tr.configure_optimizers()["optimizer"]
+    out = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        model.compute_dtype = dt
+        opt.zero_grad()
+        loss, logs = tr(model, h, z, s, None, t=t, x0=x0)
+        loss.backward()
+        torch.cuda.synchronize()
+        out[name] = (float(loss.detach()), model.arena.grad.clone(), {k: float(v) for k, v in logs.items()})
+    model.compute_dtype = None
+    (l32, g32, logs32), (l16, g16, logs16) = out["f32"], out["bf16"]
+    assert math.isfinite(l16) and abs(l16 - l32) <= 3e-3 * abs(l32), (l16, l32)
+    for k in ("osl", "del", "u_mape"):
+        assert abs(logs16[k] - logs32[k]) <= 1e-2 * abs(logs32[k]) + 1e-4, (k, logs16[k], logs32[k])
+    n32, n16 = float(g32.double().norm()), float(g16.double().norm())
+    assert abs(n16 - n32) <= 2e-2 * n32, (n16, n32)
+    cos = float((g32.double() * g16.double()).sum() / (n32 * n16))
+    assert cos > 0.999, cos
+    worst = 0.0
+    for seg, (a, b) in model.arena.segments(model.args.backbone_args.depth).items():
+        e = rel(g16[a:b], g32[a:b])
+        worst = max(worst, e)
+        assert e < 6e-2, (seg, e)
+    print(f"[B={B} L={L}] bf16 vs fp32 step: loss {l16:.5f} / {l32:.5f}, |g| {n16:.4f} / {n32:.4f}, cos {cos:.6f}, worst segment rel-L2 {worst:.3e}")
 
 
 def test_sampler_graph_equals_eager_config3(dev):

@@ -510,3 +510,42 @@ def test_optimizer(dev):
     assert torch.allclose(p.cpu(), P["w"], rtol=1e-5, atol=1e-7)
     assert torch.allclose(ema.cpu(), Eo["w"], rtol=1e-5, atol=1e-7)
     assert torch.allclose(v.cpu(), Vo["w"], rtol=1e-5, atol=1e-9)
+
+
+def test_rope_table_long_positions(dev):
+    """od_rope_table at BASELINE configs[4]'s length against the REFERENCE's own angles (tests/golden/rope_long.npz, rows
+    sub-sampled): at position 32767 one ulp of a high inverse frequency is already 2e-3 rad, so the table must not depend
+    on a fast device powf.  Then q/k norm + RoPE through od_qk_norm_rope on those rows against the reference's rope()."""
+    import numpy as np
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "rope_long.npz"))
+    N, D = int(z["N"]), int(z["D"])
+    pos = torch.from_numpy(z["pos"]).long()
+    ang = torch.from_numpy(z["angle"])
+    table = torch.zeros(N, D // 2, 2, device=dev)
+    ops.rope_table(table, N, D)
+    t = table.cpu()[pos]
+    # cos/sin of the reference's fp32 angle, evaluated in double: the table may differ by the device's cosf/sinf rounding and
+    # by <= 1 ulp of inv_freq at the two low frequencies where torch's own fp32 pow is not correctly rounded (<= 8e-6 rad)
+    assert float((t[..., 0].double() - ang.double().cos()).abs().max()) < 1e-5
+    assert float((t[..., 1].double() - ang.double().sin()).abs().max()) < 1e-5
+    if dev.type != "cuda":
+        return                       # the norm + RoPE kernel over 32768 frames is a GPU-sized launch
+    H = 2
+    x = torch.from_numpy(z["x"])                       # (1, H, P, D) at rows `pos`
+    qkv = torch.zeros(N, 3 * H * D)
+    qkv[pos, : H * D] = x[0].permute(1, 0, 2).reshape(len(pos), H * D)
+    qkv[pos, H * D: 2 * H * D] = qkv[pos, : H * D]
+    qkv = qkv.to(dev)
+    ones = torch.ones(D, device=dev)
+    out = torch.zeros(N, 2 * H * D, device=dev)
+    eps = torch.finfo(torch.float32).eps
+    ops.qk_norm_rope(qkv, ones, ones, table, out, 1, N, H, D, eps)
+    # reference: rope(q_norm(x)) with unit gain; the fixture's y = rope(x), and rope is linear per position, so
+    # rope(x * r) = y * r with r the per-(row, head) inverse RMS
+    y = torch.from_numpy(z["y"])[0]                    # (H, P, D)
+    r = torch.rsqrt(x[0].pow(2).mean(-1, keepdim=True) + eps)
+    want = (y * r).permute(1, 0, 2).reshape(len(pos), H * D)
+    got = out.cpu()[pos]
+    assert rel_l2(got[:, : H * D], want) < 2e-6 and rel_l2(got[:, H * D:], want) < 2e-6
+    assert float((got[:, : H * D] - want).abs().max()) < 2e-5

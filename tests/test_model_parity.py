@@ -200,3 +200,127 @@ def test_edge_shapes_vs_oracle(dev, B, L, Ba, steps):
         assert float(loss.detach()) == pytest.approx(float(ref_loss), rel=5e-5)
         for k, p in tr.diffusion.named_parameters():
             assert rel_l2(p.grad, ref_grads[k]) < 1e-3, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16 training step (model.yml:12 `precision: bf16-mixed` — what the headline bench runs) against the reference's own
+# bf16-autocast loss and gradients.  Bound per tensor: error vs the reference's fp32 gradient <= BF16_K x the error of the
+# reference's own bf16 run on that tensor (+ a floor for tensors where the reference's bf16 error is tiny).
+BF16_K, BF16_FLOOR = 3.0, 4e-3
+
+
+def run_bf16_training_case(name, dev):
+    fx = load(name)
+    d = dims_of(fx)
+    seed = int(fx["seed"])
+    P = O.init_params(d, seed=seed)
+    data = O.synthetic_batch(d, int(fx["B"]), int(fx["L"]), seed=seed + 1)
+    tr = make_trainer(d, P, dev)
+    model = tr.diffusion
+    model.compute_dtype = torch.bfloat16
+    dd = {k: v.to(dev) for k, v in data.items()}
+    opt = tr.configure_optimizers()["optimizer"]
+    opt.zero_grad()
+    loss, logs = tr(model, dd["h"], dd["z"], dd["s"], None, t=fx["t_used"].to(dev), x0=dd["x0"])
+    loss.backward()
+    ref32, ref16 = float(fx["f32.loss"]), float(fx["bf16.loss"])
+    assert abs(float(loss.detach()) - ref32) <= BF16_K * abs(ref16 - ref32) + 2e-3 * ref32, (float(loss.detach()), ref32, ref16)
+    gn = float(model.arena.grad.double().norm())
+    gn32, gn16 = float(fx["f32.grad_norm"]), float(fx["bf16.grad_norm"])
+    assert abs(gn - gn32) <= BF16_K * abs(gn16 - gn32) + 5e-3 * gn32, (gn, gn32, gn16)
+    ratios = []
+    for k, p in model.named_parameters():
+        g = p.grad.detach().cpu()
+        if "f32.grad." + k in fx:
+            r32, r16 = fx["f32.grad." + k], fx["bf16.grad." + k]
+            mine = g
+        else:                                    # full-width fixture: strided sub-sample + norm
+            r32, r16 = fx["f32.gradsub." + k], fx["bf16.gradsub." + k]
+            n = g.numel()
+            mine = g.flatten()[::max(1, n // 64)][:64]
+            n32 = float(fx["f32.gradnorm." + k])
+            assert abs(float(g.norm()) - n32) <= BF16_K * abs(float(fx["bf16.gradnorm." + k]) - n32) + 2e-2 * n32 + 1e-7, k
+        if float(r32.norm()) == 0:
+            continue
+        e_ref, e_mine = rel_l2(r16, r32), rel_l2(mine, r32)
+        assert e_mine <= BF16_K * e_ref + BF16_FLOOR, (k, e_mine, e_ref)
+        ratios.append(e_mine / max(e_ref, 1e-9))
+    print(f"[{name}] bf16 step: loss {float(loss.detach()):.5f} (ref fp32 {ref32:.5f}, ref bf16 {ref16:.5f}); "
+          f"median grad error = {float(np.median(ratios)):.2f} x the reference's own bf16 error, worst {max(ratios):.2f} x")
+
+
+@pytest.mark.parametrize("name", ["train_bf16_tiny_b3_l40"])
+def test_bf16_training_step_tiny(dev, name):
+    run_bf16_training_case(name, dev)
+
+
+@pytest.mark.gpu
+def test_bf16_training_step_full_width():
+    from osu_dreamer_amd import _lib
+    _lib._lib = None
+    _lib.lib()
+    run_bf16_training_case("train_bf16_full_d2_b2_l96", torch.device("cuda:0"))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# validation_step (train.py:128-139) against the reference's logs: segmenting of the full map, EMA weights, no_grad
+def run_validation_case(name, dev):
+    fx = load(name)
+    d = dims_of(fx)
+    seed = int(fx["seed"])
+    tr = DiffusionTrainer(val_batches=int(fx["val_batches"]), opt_args=dict(lr=3e-4, weight_decay=0.01),
+                          schedule_args=LRScheduleArgs(warmup_init=.3, warmup_steps=1000, decay_start=30000),
+                          osl_weight=1., del_weight=30., emb_dim=d.emb_dim, a_dim=d.a_dim, style_dim=d.style_dim,
+                          diffusion_args=margs(d))
+    tr.diffusion.load_state_dict(O.init_params(d, seed=seed))
+    tr.diffusion_ema.module.load_state_dict(O.init_params(d, seed=seed + 7))     # the EMA copy has its own weights
+    tr = tr.to(dev)
+    batch = tuple(fx[k].to(dev) for k in ("h", "z", "s", "labels"))
+    logs = tr.validation_step(batch, 0, t=fx["t_used"].to(dev), x0=fx["x0"].to(dev))
+    for k in ("loss", "osl", "del", "u_mape"):
+        assert float(logs[k]) == pytest.approx(float(fx["log.val_" + k]), rel=1e-4), k
+        assert float(tr._logged["val/" + k]) == float(logs[k])
+    assert not any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in tr.diffusion_ema.module.parameters())
+
+
+def test_validation_step_tiny(dev):
+    run_validation_case("val_tiny", dev)
+
+
+@pytest.mark.gpu
+def test_validation_step_full_width():
+    from osu_dreamer_amd import _lib
+    _lib._lib = None
+    _lib.lib()
+    run_validation_case("val_full_d2", torch.device("cuda:0"))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# a cached sampler hipGraph must not outlive the buffers it captured.  sample(A) -> a train step /
+# forward with another shape (re-plans: new workspace, re-packed weights) -> sample(A) again has an EQUAL plan key but
+# different allocations; the second call must re-capture (engine.generation) and still equal the eager sampler.
+def test_sampler_graph_survives_replanning(dev):
+    d = O.TINY
+    P = O.init_params(d, seed=77)
+    data = O.synthetic_batch(d, 2, 40, seed=78)
+    tr = make_trainer(d, P, dev)
+    m = tr.diffusion
+    dd = {k: v.to(dev) for k, v in data.items()}
+    x1 = m.sample(dd["h"], dd["s"], 4, x_init=dd["x_init"])
+    gen1 = m.engine.generation
+    other = O.synthetic_batch(d, 3, 24, seed=79)
+    oo = {k: v.to(dev) for k, v in other.items()}
+    loss, _ = tr(m, oo["h"], oo["z"], oo["s"], None, t=oo["t"], x0=oo["x0"])       # train=True plan, another shape
+    loss.backward()
+    with torch.no_grad():
+        m(oo["h"], oo["s"], oo["x_init"])                                         # no-grad plan, another shape
+    x2 = m.sample(dd["h"], dd["s"], 4, x_init=dd["x_init"])
+    assert m.engine.generation > gen1
+    m.use_graph = False
+    x3 = m.sample(dd["h"], dd["s"], 4, x_init=dd["x_init"])
+    m.use_graph = True
+    assert torch.equal(x2, x3) and torch.equal(x1, x3)
+    ref = O.sample(data["h"], data["s"], 4, data["x_init"], P, d)[0]
+    assert rel_l2(x2, ref) < 1e-4
+    # requires_grad survives .to(): the EMA copy stays frozen
+    assert not any(p.requires_grad for p in tr.diffusion_ema.module.parameters())

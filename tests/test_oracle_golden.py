@@ -107,6 +107,59 @@ def test_forward_sample_train(name):
             assert torch.allclose(sub, fx["ema2sub." + k], rtol=1e-4, atol=2e-6), k
 
 
+@pytest.mark.parametrize("name", ["val_tiny", "val_full_d2"])
+def test_validation_step_vs_reference(name):
+    """train.py:128-139: segmenting of the full map, EMA weights, no_grad loss."""
+    torch.set_num_threads(8)
+    fx = load(name)
+    d = dims_of(fx)
+    seed = int(fx["seed"])
+    P_ema = O.init_params(d, seed=seed + 7)          # the generator gave the EMA copy its own weights
+    logs = O.validation_step(P_ema, d, fx["h"], fx["z"], fx["s"], fx["labels"], int(fx["val_batches"]), fx["t_used"], fx["x0"])
+    for k in ("loss", "osl", "del", "u_mape"):
+        assert float(logs[k]) == pytest.approx(float(fx["log.val_" + k]), rel=5e-5), k
+    # the live model's weights give a different loss: the fixture can tell the two apart
+    wrong = O.validation_step(O.init_params(d, seed=seed), d, fx["h"], fx["z"], fx["s"], fx["labels"], int(fx["val_batches"]),
+                              fx["t_used"], fx["x0"])
+    assert abs(float(wrong["loss"]) - float(fx["log.val_loss"])) > 1e-2 * float(fx["log.val_loss"])
+
+
+def test_rope_long_positions():
+    """rope() at configs[4]'s length (positions up to 32767), sub-sampled rows."""
+    fx = load("rope_long")
+    N, D = int(fx["N"]), int(fx["D"])
+    pos = fx["pos"].long()
+    x = torch.zeros(1, 2, N, D)
+    x[:, :, pos] = fx["x"]
+    y = O.rope_half_split(x)[:, :, pos]
+    assert torch.equal(y, fx["y"]) or rel_l2(y, fx["y"]) < 1e-7
+    # the angle table itself (what od_rope_table must reproduce): l * 10000^(-2j/D) in fp32
+    inv = 10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / -D)
+    assert torch.equal(inv, fx["inv_freq"])
+    assert torch.equal(torch.outer(pos.float(), inv), fx["angle"])
+
+
+def test_bf16_training_fixture_is_anchored():
+    """The bf16-autocast loss / gradients of the reference sit next to its fp32 ones on the same inputs; the fp32 half
+    must be the very numbers of the round-1 fixture, and the bf16 half must differ from it by a bf16-sized amount."""
+    for name, base in (("train_bf16_tiny_b3_l40", "tiny_b3_l40"), ("train_bf16_full_d2_b2_l96", "full_d2_b2_l96")):
+        fx, fb = load(name), load(base)
+        assert float(fx["f32.loss"]) == pytest.approx(float(fb["loss"]), rel=1e-6)
+        assert torch.allclose(fx["t_used"], fb["t_used"])
+        assert float(fx["f32.grad_norm"]) == pytest.approx(float(fb["grad_norm"]), rel=1e-5)
+        e = abs(float(fx["bf16.loss"]) - float(fx["f32.loss"])) / float(fx["f32.loss"])
+        assert 1e-6 < e < 2e-2
+        errs = []
+        for k in fx:
+            if k.startswith("bf16.grad."):
+                errs.append(rel_l2(fx[k], fx["f32.grad." + k[len("bf16.grad."):]]))
+            elif k.startswith("bf16.gradsub."):
+                ref = fx["f32.gradsub." + k[len("bf16.gradsub."):]]
+                if float(ref.norm()) > 0:
+                    errs.append(rel_l2(fx[k], ref))
+        assert errs and 1e-4 < float(np.median(errs)) < 5e-2
+
+
 def test_reference_bf16_error_is_recorded():
     """The fixture carries the reference's own bf16-autocast output so the GPU bf16
     tolerance is anchored to what the reference itself loses in bf16."""
