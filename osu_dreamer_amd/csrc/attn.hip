@@ -280,6 +280,459 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
     }
 }
 
+// ======================================================================== forward, bf16, head_dim 64, 32x32x16 MFMA
+// Round-2 rewrite of the bf16 hot path, driven by the issue-model probe (tools/probes/issue_model.hip ->
+// profiles/r02a_issue_model.txt): a gfx950 SIMD issues ONE instruction per ~4.2-4.5 cycles whatever its kind and however
+// many waves it holds (v_exp_f32 ~8.5, an MFMA ~9.5 of issue while its pipe runs 16 / 32 cycles in the background), so a
+// softmax-carrying loop is bound by its instruction COUNT.  v_mfma_f32_32x32x16_bf16 does the work of two 16x16x32 for one
+// issue slot: 16 MFMAs per (32 queries x 64 keys) instead of 32.  Same formulation as above (S^T = K Q^T with the softmax
+// row as the accumulator COLUMN, P^T accumulators feeding O^T += V^T P^T through a key permutation that the V operand
+// reproduces with transpose reads), on 32-wide tiles:
+//   accumulator element r of lane (c = lane & 31, hi = lane >> 5): row (r & 3) + 8 (r >> 2) + 4 hi, column c
+//   k-slot 8 hi + j of key slab sl (16 keys) of key block kb (32 keys)  <->  key 32 kb + 16 sl + 8 (j >> 2) + 4 hi + (j & 3)
+// The running max is gone from the common path: p = 2^(s - ref) against the lazy per-query reference, and the lane-local
+// partial row sum (needed anyway) doubles as the overflow guard — only if a partial sum leaves [0, 2^OD_FWD32_GUARD) does the
+// wave take the exact path (true row max, reference raised, O and l rescaled, p recomputed).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16_t od_mma32(s16x8 a, s16x8 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#ifndef OD_FWD32_GUARD
+#define OD_FWD32_GUARD 16384.0f
+#endif
+
+#ifndef OD_FWD32_OCC2
+#define OD_FWD32_OCC2 2     // waves per SIMD asked of the register allocator at 64 queries per wave
+#endif
+template <int NW, int NQB, bool PRE>
+__global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash_fwd32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                                 const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
+                                                                 float* __restrict__ lse, int B, int H, int L, float scale) {
+    using St = Stage<bf16_t, 64>;
+    constexpr int HD = 64, QB = NW * NQB * 32, STAGE = 2 * St::BYTES;
+    static_assert(NW == 4, "the K/V tiles are streamed as 2 + 2 one-KiB pieces per wave");
+    OD_DYN_SMEM(smem);   // 2 stages x (K row-major, V row-major), 16-byte slots XOR-swizzled by row
+    const int nqt = (L + QB - 1) / QB;
+    int qt, bh;
+    if (!attn_block_coords(nqt, B * H, qt, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
+    const bf16_t* qb_ = q + (size_t)b * L * ldq + h * HD;
+    const int q0 = qt * QB + wave * NQB * 32;
+    const float c = PRE ? 1.f : scale * LOG2E, inv_c = 1.0f / c;
+
+    // K / V tiles by buffer-addressed LDS-DMA: per-lane offset fixed for the whole kernel, one scalar add per tile;
+    // rows >= L lie past the end of the descriptor and read as zero
+    const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
+    const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
+    // piece = 8 rows x 128 B; the swizzle (swz32, od_tiles.h) is applied on the SOURCE column; a wave's two pieces (w, w + 4)
+    // have the same row bits 3..0, so one per-lane offset serves both
+    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
+    const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
+    auto dma = [&](int kt, unsigned char* st) {
+        const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u, sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
+        od_buffer_lds16(rk, vk, sk, st + wave * 1024);
+        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
+        od_buffer_lds16(rv, vv, sv, st + St::BYTES + wave * 1024);
+        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + St::BYTES + (wave + 4) * 1024);
+    };
+
+    // Q^T fragments (B operand): column = query, k = 16 s + 8 hi + j
+    s16x8 fq[NQB][4];
+#pragma unroll
+    for (int qi = 0; qi < NQB; qi++) {
+        int row = q0 + qi * 32 + c32; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) fq[qi][s4] = *(const s16x8*)(qb_ + (size_t)row * ldq + s4 * 16 + hi * 8);
+    }
+    f32x16_t oacc[NQB][2], minit[NQB];      // minit = splat(-reference): the score MFMAs' C operand, touched on the exact path only
+    float mref[NQB], lrun[NQB];
+#pragma unroll
+    for (int qi = 0; qi < NQB; qi++) {
+        mref[qi] = 0.f; lrun[qi] = 0.f;
+        minit[qi] = (f32x16_t)(0.f);
+        oacc[qi][0] = (f32x16_t)(0.f); oacc[qi][1] = (f32x16_t)(0.f);
+    }
+    const int nkt = (L + 63) / 64;
+    // lane-constant LDS byte offsets inside a stage: K fragment (key row c32 (+32), 16-byte slot 2 s + hi) and V transpose-read
+    // chunk (rows 4 (g4 >> 1) + (x >> 2) (+8, +16, ...) of the tile, feature column 16 (g4 & 1) + 4 (x & 3) (+32))
+    int offK[4], offV[2][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) offK[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);                // + kb * 32 rows = + 4096 B
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int e = 0; e < 2; e++)                                                                  // + 16 rows per slab = + 2048 B
+            offV[db][e] = St::BYTES + tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+    dma(0, smem);
+    __syncthreads();
+
+    auto tile = [&](int kt, const unsigned char* st, unsigned char* st_next, auto masked_t, auto first_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        constexpr bool FIRST = decltype(first_t)::value;
+#ifdef OD_FWD32_TRACE
+        // debug build only: shader-clock stamps of one wave around the phases of tiles 32..39, written behind the lse array
+        const bool tr_on = blockIdx.x == OD_FWD32_TRACE && wave == 0 && kt >= 32 && kt < 40;
+        long long* tr_buf = (long long*)(lse + (size_t)B * H * L) + (kt - 32) * 8;
+#define TR(i) do { __builtin_amdgcn_sched_barrier(0); if (tr_on) { const long long tt = __builtin_readcyclecounter(); if (lane == 0) tr_buf[i] = tt; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TR(i) do { } while (0)
+#endif
+        TR(0);
+        if (kt + 1 < nkt) dma(kt + 1, st_next);
+        TR(1);
+
+        f32x16_t sa[NQB][2];
+        auto scores = [&]() {       // S^T blocks (rows = keys); the accumulators start at -reference
+            s16x8 fk[2][4];
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) fk[kb][s4] = *(const s16x8*)(st + offK[s4] + kb * 4096);
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int qi = 0; qi < NQB; qi++) {
+                    sa[qi][kb] = od_mma32(fk[kb][0], fq[qi][0], minit[qi]);
+#pragma unroll
+                    for (int s4 = 1; s4 < 4; s4++) sa[qi][kb] = od_mma32(fk[kb][s4], fq[qi][s4], sa[qi][kb]);
+                    if constexpr (!PRE) sa[qi][kb] = sa[qi][kb] * c + minit[qi] * (1.f - c);    // (q.k) c - reference
+                    if constexpr (MASKED) {    // ragged last tile only: keys >= L
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            if (kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) sa[qi][kb][r] = NEG_BIG;
+                    }
+                }
+            }
+        };
+#ifndef OD_FWD32_PRIO
+#define OD_FWD32_PRIO 0      // 1: raise the wave's priority while it feeds the matrix pipe; 2: while it runs the softmax instead
+#endif
+        if (OD_FWD32_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+        scores();
+        if (OD_FWD32_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (OD_FWD32_PRIO == 2) __builtin_amdgcn_s_setprio(2);
+        TR(2);
+        // exact path: move the reference to the row maximum (always on the first tile; otherwise only when the guard trips)
+        auto exact = [&]() {
+#pragma unroll
+            for (int qi = 0; qi < NQB; qi++) {
+                float m = NEG_BIG;
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) m = fmaxf(m, sa[qi][kb][r]);
+                m = fmaxf(m, __shfl_xor(m, 32));               // the two half-waves hold complementary keys of the same query
+                const float d = FIRST ? m : fmaxf(m, 0.f);     // scores are relative to the current reference
+                if constexpr (!FIRST) {
+                    const float alpha = od_exp2(-d);
+                    lrun[qi] *= alpha;
+                    oacc[qi][0] *= alpha; oacc[qi][1] *= alpha;
+                }
+                mref[qi] += d;                                 // log2 units
+                minit[qi] = (f32x16_t)(-mref[qi]);
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) sa[qi][kb] -= d;
+            }
+        };
+        s16x8 fp[NQB][2][2];
+        float ps[NQB];
+        auto probs = [&]() {
+#pragma unroll
+            for (int qi = 0; qi < NQB; qi++) {
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        u32x4 w;
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) {
+                            const float p0 = od_exp2(sa[qi][kb][8 * sl + 2 * jj]), p1 = od_exp2(sa[qi][kb][8 * sl + 2 * jj + 1]);
+                            acc0 += p0; acc1 += p1;
+                            w[jj] = od_pack_bf2(p0, p1);
+                        }
+                        fp[qi][kb][sl] = __builtin_bit_cast(s16x8, w);
+                    }
+                ps[qi] = acc0 + acc1;
+            }
+        };
+        if constexpr (FIRST) { exact(); probs(); }
+        else {
+            probs();
+            bool bad = false;
+#pragma unroll
+            for (int qi = 0; qi < NQB; qi++) bad |= !(ps[qi] < OD_FWD32_GUARD);
+            if (__any(bad)) { exact(); probs(); }       // wave-uniform, rare
+        }
+#pragma unroll
+        for (int qi = 0; qi < NQB; qi++) lrun[qi] += ps[qi];
+        TR(3);
+        if (OD_FWD32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if (OD_FWD32_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+        // O^T += V^T P^T : A = V^T fragment (rows = features of block db), two transpose reads per 16-key slab
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    const s16x4 a0 = od_lds_tr_read((const bf16_t*)(st + offV[db][0] + (kb * 2 + sl) * 2048));
+                    const s16x4 a1 = od_lds_tr_read((const bf16_t*)(st + offV[db][1] + (kb * 2 + sl) * 2048));
+                    s16x8 fv;
+                    fv[0] = a0[0]; fv[1] = a0[1]; fv[2] = a0[2]; fv[3] = a0[3];
+                    fv[4] = a1[0]; fv[5] = a1[1]; fv[6] = a1[2]; fv[7] = a1[3];
+#pragma unroll
+                    for (int qi = 0; qi < NQB; qi++) oacc[qi][db] = od_mma32(fv, fp[qi][kb][sl], oacc[qi][db]);
+                }
+        TR(4);
+        if (OD_FWD32_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        TR(5);
+    };
+    // the two LDS stages alternate with compile-time addresses: the loop body is unrolled by two
+    unsigned char* const s0 = smem;
+    unsigned char* const s1 = smem + STAGE;
+    const int nfull = L / 64;
+    if (nfull > 0) tile(0, s0, s1, std::false_type{}, std::true_type{});
+    else tile(0, s0, s1, std::true_type{}, std::true_type{});
+    int kt = 1;
+    for (; kt + 1 < nfull; kt += 2) {
+        tile(kt, s1, s0, std::false_type{}, std::false_type{});
+        tile(kt + 1, s0, s1, std::false_type{}, std::false_type{});
+    }
+    if (kt < nfull) { tile(kt, s1, s0, std::false_type{}, std::false_type{}); kt++; }
+    if (nfull > 0 && nfull < nkt) { if (kt & 1) tile(kt, s1, s0, std::true_type{}, std::false_type{}); else tile(kt, s0, s1, std::true_type{}, std::false_type{}); }
+#pragma unroll
+    for (int qi = 0; qi < NQB; qi++) {
+        float l = lrun[qi];
+        l += __shfl_xor(l, 32);
+        const float inv = 1.f / l;
+        const int row = q0 + qi * 32 + c32;
+        if (row < L) {
+            bf16_t* orow = o + ((size_t)b * L + row) * ldo + h * HD;
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+                    st4(orow + db * 32 + 8 * t4 + 4 * hi, oacc[qi][db][4 * t4] * inv, oacc[qi][db][4 * t4 + 1] * inv,
+                        oacc[qi][db][4 * t4 + 2] * inv, oacc[qi][db][4 * t4 + 3] * inv);
+            if (hi == 0) lse[((size_t)b * H + h) * L + row] = (mref[qi] + log2f(l)) * LN2;
+        }
+    }
+}
+
+// ---- software-pipelined variant: the score MFMAs of tile t+1 are issued under the exponentials of tile t, and the row sums
+// of tile t under its PV MFMAs, so that ONE wave keeps both the matrix pipe and the vector ALU busy (phase_overlap probe:
+// 16 MFMAs then 64 VALU ops as two coarse phases take 904 cycles from one wave, finely interleaved 572).  Two live score tiles
+// (S_cur, S_next).  The overflow guard is delayed by one step: it looks at the partial row sums AFTER the PV MFMAs consumed
+// the tile and rescales O, l, the reference and S_next when a sum left [0, 2^14) — exact, because everything is linear in P
+// as long as no value reached inf (which needs a jump of > 2^113 inside one tile).
+#ifndef OD_FWD32_SGB
+#define OD_FWD32_SGB 1     // sched_group_barrier hints for the MFMA / VALU interleave
+#endif
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void flash_fwd32p_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                              const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
+                                                              float* __restrict__ lse, int B, int H, int L, float scale) {
+    constexpr int HD = 64, QB = 128, TB = 8192;          // TB = bytes of one 64 x 64 bf16 tile
+    OD_DYN_SMEM(smem);                                   // K0 | K1 | V0 | V1
+    const int nqt = (L + QB - 1) / QB;
+    int qt, bh;
+    if (!attn_block_coords(nqt, B * H, qt, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
+    const bf16_t* qb_ = q + (size_t)b * L * ldq + h * HD;
+    const int q0 = qt * QB + wave * 32;
+    const float c = PRE ? 1.f : scale * LOG2E;
+    const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
+    const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
+    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
+    const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
+    auto dmaK = [&](int kt, unsigned char* dst) {
+        const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u;
+        od_buffer_lds16(rk, vk, sk, dst + wave * 1024);
+        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, dst + (wave + 4) * 1024);
+    };
+    auto dmaV = [&](int kt, unsigned char* dst) {
+        const unsigned sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
+        od_buffer_lds16(rv, vv, sv, dst + wave * 1024);
+        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, dst + (wave + 4) * 1024);
+    };
+    s16x8 fq[4];
+    {
+        int row = q0 + c32; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) fq[s4] = *(const s16x8*)(qb_ + (size_t)row * ldq + s4 * 16 + hi * 8);
+    }
+    f32x16_t oacc[2], minit = (f32x16_t)(0.f);
+    oacc[0] = (f32x16_t)(0.f); oacc[1] = (f32x16_t)(0.f);
+    float mref = 0.f, lrun = 0.f;
+    const int nkt = (L + 63) / 64;
+    const bool ragged = (L & 63) != 0;
+    int offK[4], offV[2][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) offK[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) offV[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+
+    unsigned char* const K0 = smem;
+    unsigned char* const K1 = smem + TB;
+    unsigned char* const V0 = smem + 2 * TB;
+    unsigned char* const V1 = smem + 3 * TB;
+
+    auto scores = [&](const unsigned char* tK, int kt, auto mask_t, f32x16_t (&sa)[2]) __attribute__((always_inline)) {
+        s16x8 fk[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) fk[kb][s4] = *(const s16x8*)(tK + offK[s4] + kb * 4096);
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            sa[kb] = od_mma32(fk[kb][0], fq[0], minit);
+#pragma unroll
+            for (int s4 = 1; s4 < 4; s4++) sa[kb] = od_mma32(fk[kb][s4], fq[s4], sa[kb]);
+        }
+        if constexpr (!PRE) {
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) sa[kb] = sa[kb] * c + minit * (1.f - c);
+        }
+        if constexpr (decltype(mask_t)::value) {      // the ragged last tile only
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) sa[kb][r] = NEG_BIG;
+        }
+    };
+    // move the reference by d (log2 units): O, l and any score tile already computed are rescaled
+    auto shift = [&](float d, f32x16_t (*pending)[2]) __attribute__((always_inline)) {
+        const float alpha = od_exp2(-d);
+        lrun *= alpha;
+        oacc[0] *= alpha; oacc[1] *= alpha;
+        mref += d;
+        minit = (f32x16_t)(-mref);
+        if (pending) { (*pending)[0] -= d; (*pending)[1] -= d; }
+    };
+
+    dmaK(0, K0); dmaV(0, V0);
+    if (nkt > 1) dmaK(1, K1);
+    __syncthreads();
+    f32x16_t sA[2], sB[2];
+    if (nkt == 1 && ragged) scores(K0, 0, std::true_type{}, sA); else scores(K0, 0, std::false_type{}, sA);
+    {   // initial reference: the row maximum of the first tile
+        float m = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) m = fmaxf(m, sA[kb][r]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        mref = m; minit = (f32x16_t)(-m);
+        sA[0] -= m; sA[1] -= m;
+    }
+    // one step: consumes `cur` (tile t), produces `nxt` (tile t + 1) from Kn; V tile t in Vc; DMA targets for V(t+1), K(t+2).
+    // NEXT: 0 = last tile (no successor), 1 = successor, 2 = successor is the ragged last tile; KDMA: tile t + 2 exists.
+    // The hot instance (NEXT = 1, KDMA) has no branch between the score MFMAs, the exponentials and the PV MFMAs: one
+    // scheduling region.
+    auto step = [&](int t, auto next_t, auto kdma_t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2], const unsigned char* Kn, const unsigned char* Vc,
+                    unsigned char* Vdst, unsigned char* Kdst) __attribute__((always_inline)) {
+        constexpr int NEXT = decltype(next_t)::value;
+        if constexpr (NEXT != 0) dmaV(t + 1, Vdst);
+        if constexpr (decltype(kdma_t)::value) dmaK(t + 2, Kdst);
+        // ---- phase A: S_next (MFMA) under p = 2^S_cur (transcendental)
+        if constexpr (NEXT == 1) scores(Kn, t + 1, std::false_type{}, nxt);
+        if constexpr (NEXT == 2) scores(Kn, t + 1, std::true_type{}, nxt);
+        float p[2][16];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) p[kb][r] = od_exp2(cur[kb][r]);
+#if OD_FWD32_SGB && !defined(OD_EMU)
+        if constexpr (NEXT == 1) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // the 8 K fragment reads first
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);  // 4 v_exp
+            }
+        }
+#endif
+        s16x8 fp[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                u32x4 w;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) w[jj] = od_pack_bf2(p[kb][8 * sl + 2 * jj], p[kb][8 * sl + 2 * jj + 1]);
+                fp[kb][sl] = __builtin_bit_cast(s16x8, w);
+            }
+        // ---- phase B: O^T += V^T P^T (MFMA) under the lane-partial row sums (VALU)
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    const s16x4 a0 = od_lds_tr_read((const bf16_t*)(Vc + offV[db][0] + (kb * 2 + sl) * 2048));
+                    const s16x4 a1 = od_lds_tr_read((const bf16_t*)(Vc + offV[db][1] + (kb * 2 + sl) * 2048));
+                    s16x8 fv;
+                    fv[0] = a0[0]; fv[1] = a0[1]; fv[2] = a0[2]; fv[3] = a0[3];
+                    fv[4] = a1[0]; fv[5] = a1[1]; fv[6] = a1[2]; fv[7] = a1[3];
+                    oacc[db] = od_mma32(fv, fp[kb][sl], oacc[db]);
+                }
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) { a0 += p[kb][r]; a1 += p[kb][r + 1]; a2 += p[kb][r + 2]; a3 += p[kb][r + 3]; }
+        const float ps = (a0 + a1) + (a2 + a3);
+        lrun += ps;
+        if (__any(!(ps < OD_FWD32_GUARD))) {          // wave-uniform, rare: bring the running quantities back into range
+            float d = fmaxf(log2f(fmaxf(ps, 1.f)), 0.f);
+            d = fmaxf(d, __shfl_xor(d, 32));          // one reference per query: both half-waves move together
+            shift(d, NEXT != 0 ? &nxt : nullptr);
+        }
+        __syncthreads();
+    };
+    // buffers by parity of t: K(t+1) in K[(t+1)&1], V(t) in V[t&1]; DMA V(t+1) -> V[(t+1)&1], K(t+2) -> K[t&1]
+    auto step_at = [&](int t, auto next_t, auto kdma_t) __attribute__((always_inline)) {
+        if (t & 1) step(t, next_t, kdma_t, sB, sA, K0, V1, V0, K1);
+        else step(t, next_t, kdma_t, sA, sB, K1, V0, V1, K0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    int t = 0;
+    for (; t + 3 < nkt; t += 2) {                      // both steps have a successor and a tile t + 2 to prefetch
+        step(t, I1{}, std::true_type{}, sA, sB, K1, V0, V1, K0);
+        step(t + 1, I1{}, std::true_type{}, sB, sA, K0, V1, V0, K1);
+    }
+    for (; t < nkt; t++) {
+        const bool kd = t + 2 < nkt;
+        if (t + 1 >= nkt) step_at(t, I0{}, std::false_type{});
+        else if (t + 2 == nkt && ragged) step_at(t, I2{}, std::false_type{});
+        else if (kd) step_at(t, I1{}, std::true_type{});
+        else step_at(t, I1{}, std::false_type{});
+    }
+    {
+        float l = lrun;
+        l += __shfl_xor(l, 32);
+        const float inv = 1.f / l;
+        const int row = q0 + c32;
+        if (row < L) {
+            bf16_t* orow = o + ((size_t)b * L + row) * ldo + h * HD;
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+                    st4(orow + db * 32 + 8 * t4 + 4 * hi, oacc[db][4 * t4] * inv, oacc[db][4 * t4 + 1] * inv, oacc[db][4 * t4 + 2] * inv,
+                        oacc[db][4 * t4 + 3] * inv);
+            if (hi == 0) lse[((size_t)b * H + h) * L + row] = (mref + log2f(l)) * LN2;
+        }
+    }
+}
+
 // ======================================================================== backward
 // delta[b][h][l] = sum_d dO*O  — one wave per frame row, lanes over (h, d) chunks of 8
 template <class T>
@@ -611,12 +1064,332 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
     }
 }
 
+// ======================================================================== backward, bf16, head_dim 64, 32x32x16 MFMA
+// The two-kernel backward (dK/dV owned by key tiles, dQ by query tiles: no atomics, deterministic) on 32-wide MFMA tiles,
+// with the same trims as the forward: buffer-addressed LDS-DMA (one scalar add per tile), compile-time LDS stage addresses
+// (loops unrolled by two), swz32 tiles that serve both the contiguous and the transposed fragment reads without bank
+// conflicts.  Accumulators start at -lse / -delta (the MFMA's C operand), P = 2^acc, dS' = P * acc'.
+//
+// dK, dV: block = 4 waves x 32 keys; loop over 64-query tiles.
+//   S = Q K^T (rows = queries, cols = keys) ; dP = dO V^T ; dV^T += dO^T P ; dK^T += Q^T dS
+// P / dS accumulators (rows = queries) feed the second pair of MFMAs as B operands through the query permutation
+//   k-slot 8 hi + j of slab sl of query block qb  <->  query 32 qb + 16 sl + 8 (j >> 2) + 4 hi + (j & 3)
+// which the A operands (dO^T, Q^T) reproduce with transpose reads of the row-major tiles.
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dkv32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                                 const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int lddo,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                 bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv,
+                                                                 int B, int H, int L, float scale) {
+    constexpr int HD = 64, KB = 128, TB = 8192, STAGE = 2 * TB + 512;       // Q tile | dO tile | -lse' (64) | -delta (64)
+    OD_DYN_SMEM(smem);
+    const int nkt = (L + KB - 1) / KB;
+    int ktile, bh;
+    if (!attn_block_coords(nkt, B * H, ktile, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
+    const bf16_t* kb_ = k + (size_t)b * L * ldk + h * HD;
+    const bf16_t* vb_ = v + (size_t)b * L * ldv + h * HD;
+    const float* lseb = lse + ((size_t)b * H + h) * L;
+    const float* delb = delta + ((size_t)b * H + h) * L;
+    const int key0 = ktile * KB + wave * 32;
+    const float c = scale * LOG2E, inv_scale = PRE ? LOG2E : 1.0f / scale, out_scale = PRE ? LN2 : scale;
+
+    const od_srd_t rq = od_make_srd(q + (size_t)b * L * ldq + h * HD, (unsigned)(((size_t)(L - 1) * ldq + HD) * 2));
+    const od_srd_t rdo = od_make_srd(dout + (size_t)b * L * lddo + h * HD, (unsigned)(((size_t)(L - 1) * lddo + HD) * 2));
+    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
+    const unsigned vq = (unsigned)((wave * 8 + prow) * ldq * 2 + pslot * 16), vdo = (unsigned)((wave * 8 + prow) * lddo * 2 + pslot * 16);
+    auto dma = [&](int qt, unsigned char* st) {
+        const unsigned sq = (unsigned)qt * 64u * (unsigned)ldq * 2u, sd = (unsigned)qt * 64u * (unsigned)lddo * 2u;
+        od_buffer_lds16(rq, vq, sq, st + wave * 1024);
+        od_buffer_lds16(rq, vq, sq + 32u * (unsigned)ldq * 2u, st + (wave + 4) * 1024);
+        od_buffer_lds16(rdo, vdo, sd, st + TB + wave * 1024);
+        od_buffer_lds16(rdo, vdo, sd + 32u * (unsigned)lddo * 2u, st + TB + (wave + 4) * 1024);
+    };
+    // K, V fragments (B operands): column = key, k = 16 s + 8 hi + j
+    s16x8 fk[4], fv[4];
+    {
+        int row = key0 + c32; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            fk[s4] = *(const s16x8*)(kb_ + (size_t)row * ldk + s4 * 16 + hi * 8);
+            fv[s4] = *(const s16x8*)(vb_ + (size_t)row * ldv + s4 * 16 + hi * 8);
+        }
+    }
+    f32x16_t dkacc[2], dvacc[2];
+#pragma unroll
+    for (int db = 0; db < 2; db++) { dkacc[db] = (f32x16_t)(0.f); dvacc[db] = (f32x16_t)(0.f); }
+    int offR[4], offT[2][2];        // contiguous fragment (row c32 (+32), slot 2 s + hi) and transpose-read chunk offsets inside a tile
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) offR[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) offT[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+    const int nqt = (L + 63) / 64;
+    float r_lse = 0.f, r_del = 0.f;
+    auto gload_small = [&](int qt) {
+        if (threadIdx.x < 64) {
+            const int row = qt * 64 + threadIdx.x;
+            r_lse = row < L ? lseb[row] : 0.f;
+            r_del = row < L ? delb[row] : 0.f;
+        }
+    };
+    auto lstore_small = [&](unsigned char* st) {
+        float* sl = (float*)(st + 2 * TB);
+        if (threadIdx.x < 64) { sl[threadIdx.x] = -r_lse * inv_scale; sl[64 + threadIdx.x] = -r_del; }
+    };
+    dma(0, smem); gload_small(0); lstore_small(smem);
+    __syncthreads();
+    const bool kragged = ktile * KB + KB > L;
+    const bool kvalid = key0 + c32 < L;
+    auto tile = [&](int qt, const unsigned char* st, unsigned char* st_next, auto masked_t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        if (qt + 1 < nqt) { dma(qt + 1, st_next); gload_small(qt + 1); }
+        const unsigned char* tQ = st;
+        const unsigned char* tO = st + TB;
+        const float* s_lse = (const float*)(st + 2 * TB);
+        const float* s_del = s_lse + 64;
+        s16x8 fp[2][2], fds[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; qb++) {
+            s16x8 fqr[4], fdo[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                fqr[s4] = *(const s16x8*)(tQ + offR[s4] + qb * 4096);
+                fdo[s4] = *(const s16x8*)(tO + offR[s4] + qb * 4096);
+            }
+            f32x16_t sa, pa;       // C operands: element 4 t + i <-> query 32 qb + 8 t + 4 hi + i
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) {
+                const f32x4 l4 = *(const f32x4*)(s_lse + qb * 32 + 8 * t4 + 4 * hi);
+                const f32x4 d4 = *(const f32x4*)(s_del + qb * 32 + 8 * t4 + 4 * hi);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { sa[4 * t4 + i] = l4[i]; pa[4 * t4 + i] = d4[i]; }
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) { sa = od_mma32(fqr[s4], fk[s4], sa); pa = od_mma32(fdo[s4], fv[s4], pa); }
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) p[r] = od_exp2(PRE ? sa[r] : sa[r] * c);
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (!(kvalid && (qt * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi < L))) p[r] = 0.f;
+            }
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                u32x4 wp, wd;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int r = 8 * sl + 2 * jj;
+                    wp[jj] = od_pack_bf2(p[r], p[r + 1]);
+                    wd[jj] = od_pack_bf2(p[r] * pa[r], p[r + 1] * pa[r + 1]);
+                }
+                fp[qb][sl] = __builtin_bit_cast(s16x8, wp);
+                fds[qb][sl] = __builtin_bit_cast(s16x8, wd);
+            }
+        }
+        // dV^T += dO^T P ; dK^T += Q^T dS   (A rows = features of block db, k = permuted queries, cols = keys)
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    const int so = (qb * 2 + sl) * 2048;
+                    const s16x4 o0 = od_lds_tr_read((const bf16_t*)(tO + offT[db][0] + so));
+                    const s16x4 o1 = od_lds_tr_read((const bf16_t*)(tO + offT[db][1] + so));
+                    const s16x4 q0_ = od_lds_tr_read((const bf16_t*)(tQ + offT[db][0] + so));
+                    const s16x4 q1_ = od_lds_tr_read((const bf16_t*)(tQ + offT[db][1] + so));
+                    s16x8 fot, fqt;
+                    fot[0] = o0[0]; fot[1] = o0[1]; fot[2] = o0[2]; fot[3] = o0[3]; fot[4] = o1[0]; fot[5] = o1[1]; fot[6] = o1[2]; fot[7] = o1[3];
+                    fqt[0] = q0_[0]; fqt[1] = q0_[1]; fqt[2] = q0_[2]; fqt[3] = q0_[3]; fqt[4] = q1_[0]; fqt[5] = q1_[1]; fqt[6] = q1_[2]; fqt[7] = q1_[3];
+                    dvacc[db] = od_mma32(fot, fp[qb][sl], dvacc[db]);
+                    dkacc[db] = od_mma32(fqt, fds[qb][sl], dkacc[db]);
+                }
+        if (qt + 1 < nqt) lstore_small(st_next);
+        __syncthreads();
+    };
+    unsigned char* const s0 = smem;
+    unsigned char* const s1 = smem + STAGE;
+    const int nfull = kragged ? 0 : L / 64;
+    int qt = 0;
+    for (; qt + 1 < nfull; qt += 2) {
+        tile(qt, s0, s1, std::false_type{});
+        tile(qt + 1, s1, s0, std::false_type{});
+    }
+    if (qt < nfull) { tile(qt, s0, s1, std::false_type{}); qt++; }
+    for (; qt < nqt; qt++) { if (qt & 1) tile(qt, s1, s0, std::true_type{}); else tile(qt, s0, s1, std::true_type{}); }
+    const int row = key0 + c32;
+    if (row < L) {
+        bf16_t* dkr = dk + ((size_t)b * L + row) * lddk + h * HD;
+        bf16_t* dvr = dv + ((size_t)b * L + row) * lddv + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) {
+                st4(dkr + db * 32 + 8 * t4 + 4 * hi, dkacc[db][4 * t4] * out_scale, dkacc[db][4 * t4 + 1] * out_scale, dkacc[db][4 * t4 + 2] * out_scale,
+                    dkacc[db][4 * t4 + 3] * out_scale);
+                st4(dvr + db * 32 + 8 * t4 + 4 * hi, dvacc[db][4 * t4], dvacc[db][4 * t4 + 1], dvacc[db][4 * t4 + 2], dvacc[db][4 * t4 + 3]);
+            }
+    }
+}
+
+// dQ: block = 4 waves x 32 queries; loop over 64-key tiles.
+//   S^T = K Q^T (rows = keys, cols = queries) ; dP^T = V dO^T ; dS^T = P^T * dP^T ; dQ^T += K^T dS^T
+// The query is the accumulator column, so -lse and -delta are per-lane constants of the whole kernel: two splat C operands.
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void flash_bwd_dq32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                                const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int lddo,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                bf16_t* __restrict__ dq, int lddq, int B, int H, int L, float scale) {
+    constexpr int HD = 64, QB = 128, TB = 8192, STAGE = 2 * TB;          // K tile | V tile
+    OD_DYN_SMEM(smem);
+    const int nqt = (L + QB - 1) / QB;
+    int qtile, bh;
+    if (!attn_block_coords(nqt, B * H, qtile, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
+    const bf16_t* qb_ = q + (size_t)b * L * ldq + h * HD;
+    const bf16_t* dob = dout + (size_t)b * L * lddo + h * HD;
+    const int q0 = qtile * QB + wave * 32;
+    const float c = scale * LOG2E, inv_scale = PRE ? LOG2E : 1.0f / scale, out_scale = PRE ? LN2 : scale;
+    const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
+    const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
+    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
+    const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
+    auto dma = [&](int kt, unsigned char* st) {
+        const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u, sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
+        od_buffer_lds16(rk, vk, sk, st + wave * 1024);
+        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
+        od_buffer_lds16(rv, vv, sv, st + TB + wave * 1024);
+        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + TB + (wave + 4) * 1024);
+    };
+    s16x8 fq[4], fdo[4];
+    f32x16_t linit, dinit;
+    {
+        int row = q0 + c32; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            fq[s4] = *(const s16x8*)(qb_ + (size_t)row * ldq + s4 * 16 + hi * 8);
+            fdo[s4] = *(const s16x8*)(dob + (size_t)row * lddo + s4 * 16 + hi * 8);
+        }
+        linit = (f32x16_t)(-lse[((size_t)b * H + h) * L + row] * inv_scale);
+        dinit = (f32x16_t)(-delta[((size_t)b * H + h) * L + row]);
+    }
+    f32x16_t dqacc[2];
+    dqacc[0] = (f32x16_t)(0.f); dqacc[1] = (f32x16_t)(0.f);
+    int offR[4], offT[2][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) offR[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) offT[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+    const int nkt = (L + 63) / 64;
+    dma(0, smem);
+    __syncthreads();
+    auto tile = [&](int kt, const unsigned char* st, unsigned char* st_next, auto masked_t) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        if (kt + 1 < nkt) dma(kt + 1, st_next);
+        const unsigned char* tK = st;
+        const unsigned char* tV = st + TB;
+        s16x8 fds[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            s16x8 fkr[4], fvr[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                fkr[s4] = *(const s16x8*)(tK + offR[s4] + kb * 4096);
+                fvr[s4] = *(const s16x8*)(tV + offR[s4] + kb * 4096);
+            }
+            f32x16_t sa = od_mma32(fkr[0], fq[0], linit), pa = od_mma32(fvr[0], fdo[0], dinit);
+#pragma unroll
+            for (int s4 = 1; s4 < 4; s4++) { sa = od_mma32(fkr[s4], fq[s4], sa); pa = od_mma32(fvr[s4], fdo[s4], pa); }
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) p[r] = od_exp2(PRE ? sa[r] : sa[r] * c);
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) p[r] = 0.f;
+            }
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                u32x4 wd;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int r = 8 * sl + 2 * jj;
+                    wd[jj] = od_pack_bf2(p[r] * pa[r], p[r + 1] * pa[r + 1]);
+                }
+                fds[kb][sl] = __builtin_bit_cast(s16x8, wd);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    const int so = (kb * 2 + sl) * 2048;
+                    const s16x4 a0 = od_lds_tr_read((const bf16_t*)(tK + offT[db][0] + so));
+                    const s16x4 a1 = od_lds_tr_read((const bf16_t*)(tK + offT[db][1] + so));
+                    s16x8 fkt;
+                    fkt[0] = a0[0]; fkt[1] = a0[1]; fkt[2] = a0[2]; fkt[3] = a0[3]; fkt[4] = a1[0]; fkt[5] = a1[1]; fkt[6] = a1[2]; fkt[7] = a1[3];
+                    dqacc[db] = od_mma32(fkt, fds[kb][sl], dqacc[db]);
+                }
+        __syncthreads();
+    };
+    unsigned char* const s0 = smem;
+    unsigned char* const s1 = smem + STAGE;
+    const int nfull = L / 64;
+    int kt = 0;
+    for (; kt + 1 < nfull; kt += 2) {
+        tile(kt, s0, s1, std::false_type{});
+        tile(kt + 1, s1, s0, std::false_type{});
+    }
+    if (kt < nfull) { tile(kt, s0, s1, std::false_type{}); kt++; }
+    if (kt < nkt) { if (kt & 1) tile(kt, s1, s0, std::true_type{}); else tile(kt, s0, s1, std::true_type{}); }
+    const int row = q0 + c32;
+    if (row < L) {
+        bf16_t* dqr = dq + ((size_t)b * L + row) * lddq + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++)
+                st4(dqr + db * 32 + 8 * t4 + 4 * hi, dqacc[db][4 * t4] * out_scale, dqacc[db][4 * t4 + 1] * out_scale, dqacc[db][4 * t4 + 2] * out_scale,
+                    dqacc[db][4 * t4 + 3] * out_scale);
+    }
+}
+
 #ifndef OD_ATTN_NW
 #define OD_ATTN_NW 4      // waves per workgroup of the bf16 forward / dQ kernels.  6 (K/V streamed once per 192 queries) measured 0.71x: a 6-wave group lands 2,2,1,1 on the SIMDs and a second group no longer fits at 3 waves/SIMD
+#endif
+#ifndef OD_FWD32
+#define OD_FWD32 1        // bf16, head_dim 64: the 32x32x16 kernel (0 = the 16x16x32 kernel, kept for A/B and for hd 32 / fp32)
+#endif
+#ifndef OD_FWD32_NQB
+#define OD_FWD32_NQB 1    // 32-query blocks per wave
 #endif
 template <class T, int HD, bool PRE>
 int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* lse, int B,
                int H, int L, float scale, hipStream_t st) {
+    if constexpr (OD_FWD32 == 2 && std::is_same<T, bf16_t>::value && HD == 64) {
+        const int grid = attn_grid((L + 127) / 128, B * H);
+        OD_LAUNCH_DYN((flash_fwd32p_kernel<PRE>), dim3(grid), dim3(256), (4 * 8192), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                      (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L, scale);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
+    if constexpr (OD_FWD32 && std::is_same<T, bf16_t>::value && HD == 64) {
+        constexpr int NW = 4, NQB = OD_FWD32_NQB;
+        const int grid = attn_grid((L + NW * NQB * 32 - 1) / (NW * NQB * 32), B * H);
+        OD_LAUNCH_DYN((flash_fwd32_kernel<NW, NQB, PRE>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq,
+                      (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L, scale);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr int NW = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
     const int grid = attn_grid((L + NW * 32 - 1) / (NW * 32), B * H);
     OD_LAUNCH_DYN((flash_fwd_kernel<T, HD, NW, PRE>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
@@ -635,6 +1408,19 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 #ifndef OD_DKV_NW
 #define OD_DKV_NW 4      // waves per dK/dV workgroup (bf16): 8 = the Q/dO tiles streamed once per 256 keys
 #endif
+#ifndef OD_BWD32
+#define OD_BWD32 0        // 1: the 32x32x16 backward kernels.  Measured 26.3 ms against 25.5 ms for the 16x16x32 pair (profiles/r02e_ab_bwd.txt):
+                          // with P AND dS to convert and four operand tiles to read, the loop's non-MFMA issue time does not shrink with the MFMA count
+#endif
+    if constexpr (OD_BWD32 && std::is_same<T, bf16_t>::value && HD == 64) {
+        const int gk32 = attn_grid((L + 127) / 128, B * H);
+        OD_LAUNCH_DYN((flash_bwd_dkv32_kernel<PRE>), dim3(gk32), dim3(256), (2 * (2 * 8192 + 512)), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                      (const bf16_t*)v, ldv, (const bf16_t*)dout, lddo, lse, (const float*)delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, B, H, L, scale);
+        OD_LAUNCH_DYN((flash_bwd_dq32_kernel<PRE>), dim3(gk32), dim3(256), (4 * 8192), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                      (const bf16_t*)v, ldv, (const bf16_t*)dout, lddo, lse, (const float*)delta, (bf16_t*)dq, lddq, B, H, L, scale);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr int NWK = Stage<T, HD>::TR ? OD_DKV_NW : 4;
     const int gk = attn_grid((L + 16 * NWK * NK - 1) / (16 * NWK * NK), B * H);
     OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,

@@ -18,7 +18,9 @@ for s in $SRCS; do
     rm -f "$o"                  # a failed compile must not leave an old object for the link step
     extra=""
     # attn.hip has no NaN/Inf by construction (finite -1e30 mask): lets hipcc drop the canonicalising v_max
-    [ "$s" = "attn.hip" ] && extra="-ffinite-math-only"
+    # -fno-slp-vectorize: keeps the softmax row sums as scalar v_add_f32; SLP packs them into v_pk_add_f32, which costs more
+    # than the two adds it replaces beside MFMAs (fwd 8.85 -> 8.05 ms in one A/B run, profiles/r02c_ab_attn.txt)
+    [ "$s" = "attn.hip" ] && extra="-ffinite-math-only -fno-slp-vectorize"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c "$s" -o "$o" ${OD_HIPCC_FLAGS} &
     PIDS="$PIDS $!"
   fi

@@ -233,6 +233,32 @@ __device__ __forceinline__ void od_glds16(const void* g, void* lds) {
 }
 #endif
 
+// Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... lds): descriptor (base, byte size) + per-lane byte offset (VGPR) +
+// wave-uniform byte offset (SGPR).  The per-tile address arithmetic is then ONE scalar add instead of 64-bit vector math per
+// piece, and bytes past the end of the buffer read as zero (no row clamping for ragged tiles).  `lds` is the wave's
+// destination base (lane i lands at lds + 16 i); it must be wave-uniform.
+#if defined(OD_EMU)
+struct od_srd_t { const unsigned char* base; unsigned bytes; };
+__device__ __forceinline__ od_srd_t od_make_srd(const void* base, unsigned bytes) { return od_srd_t{(const unsigned char*)base, bytes}; }
+__device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsigned soff, void* lds) {
+    alignas(16) unsigned char tmp[16] = {0};
+    const unsigned off = voff + soff;
+    if (off + 16 <= r.bytes) memcpy(tmp, r.base + off, 16);
+    emu::global_load_lds16(tmp, (unsigned char*)lds + 16 * emu::lane_id());
+}
+__device__ __forceinline__ int od_uniform(int x) { return x; }
+#else
+typedef __amdgpu_buffer_rsrc_t od_srd_t;
+__device__ __forceinline__ od_srd_t od_make_srd(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsigned soff, void* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+// a value the program knows to be wave-uniform, told to the compiler (keeps it in an SGPR)
+__device__ __forceinline__ int od_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+#endif
+
 #define OD_CHECK_LAUNCH()                                \
     do {                                                 \
         hipError_t e__ = hipGetLastError();              \

@@ -9,6 +9,16 @@ __device__ __forceinline__ int tile_off(int row, int byte) {
     return row * ROWB + ((((byte >> 4)) ^ (row & (NS - 1))) << 4) + (byte & 15);
 }
 
+// Swizzle for 128-byte-row bf16 tiles of the 32x32x16 attention kernels, which read one image BOTH as 32-row ds_read_b128
+// fragments (a 16-lane service group touches 16 rows that are distinct mod 16) and as 32-lane-wide ds_read_b64_tr_b16 chunks
+// (4 consecutive rows x 64 bytes).  The 16-byte slot index is XORed with the bit-reversed row bits 3..1:
+//   * rows equal mod 16 only share (bank half = row & 1, slot)                      -> the b128 reads are conflict-free
+//   * rows r and r + 2 (same bank half) land in different groups of four slots      -> so are the transpose reads
+// (the 16-row kernels' key `row & 7` puts rows r and r + 8, resp. the two row pairs of a 64-byte-wide chunk, on the same banks:
+// SQ_LDS_BANK_CONFLICT was a third of the LDS cycles of the first 32x32 forward, profiles/r02d_pmc_attn.txt)
+__device__ __forceinline__ int swz32(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+__device__ __forceinline__ int tile32_off(int row, int byte) { return row * 128 + ((((byte >> 4)) ^ swz32(row)) << 4) + (byte & 15); }
+
 // 8 k-contiguous elements of `row` starting at element k0 (multiple of 8)
 template <int ROWB>
 __device__ __forceinline__ void frag_contig(od_frag<bf16_t>& f, const unsigned char* t, int row, int k0) {

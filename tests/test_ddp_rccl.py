@@ -81,6 +81,8 @@ def test_ddp_step_world1_equals_plain_step(pg):
         outs.append((float(loss.detach()), tr.diffusion.arena.data.clone(), tr.diffusion_ema.module.arena.data.clone()))
         if red is not None:
             red.close()
-    assert outs[0][0] == outs[1][0]
-    # weight-gradient GEMMs accumulate with fp32 atomics, so two runs differ in the last bits; the exchange itself adds nothing
-    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7)
+    # weight-gradient GEMMs accumulate with fp32 atomics, so two runs of the SAME step differ in the last bits (and the second
+    # step's bf16 forward amplifies that to ~1e-5 of the loss); the exchange itself must add nothing beyond that
+    assert abs(outs[0][0] - outs[1][0]) <= 2e-4 * abs(outs[0][0])
+    for a, b in ((outs[0][1], outs[1][1]), (outs[0][2], outs[1][2])):
+        assert float((a - b).norm() / b.norm()) < 1e-5
