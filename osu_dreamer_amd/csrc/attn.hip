@@ -365,22 +365,13 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
         for (int e = 0; e < 2; e++)                                                                  // + 16 rows per slab = + 2048 B
             offV[db][e] = St::BYTES + tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
     dma(0, smem);
+    OD_WAIT_VMCNT(0);
     __syncthreads();
 
     auto tile = [&](int kt, const unsigned char* st, unsigned char* st_next, auto masked_t, auto first_t) {
         constexpr bool MASKED = decltype(masked_t)::value;
         constexpr bool FIRST = decltype(first_t)::value;
-#ifdef OD_FWD32_TRACE
-        // debug build only: shader-clock stamps of one wave around the phases of tiles 32..39, written behind the lse array
-        const bool tr_on = blockIdx.x == OD_FWD32_TRACE && wave == 0 && kt >= 32 && kt < 40;
-        long long* tr_buf = (long long*)(lse + (size_t)B * H * L) + (kt - 32) * 8;
-#define TR(i) do { __builtin_amdgcn_sched_barrier(0); if (tr_on) { const long long tt = __builtin_readcyclecounter(); if (lane == 0) tr_buf[i] = tt; } __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define TR(i) do { } while (0)
-#endif
-        TR(0);
         if (kt + 1 < nkt) dma(kt + 1, st_next);
-        TR(1);
 
         f32x16_t sa[NQB][2];
         auto scores = [&]() {       // S^T blocks (rows = keys); the accumulators start at -reference
@@ -405,14 +396,7 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
                 }
             }
         };
-#ifndef OD_FWD32_PRIO
-#define OD_FWD32_PRIO 0      // 1: raise the wave's priority while it feeds the matrix pipe; 2: while it runs the softmax instead
-#endif
-        if (OD_FWD32_PRIO == 1) __builtin_amdgcn_s_setprio(2);
         scores();
-        if (OD_FWD32_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        if (OD_FWD32_PRIO == 2) __builtin_amdgcn_s_setprio(2);
-        TR(2);
         // exact path: move the reference to the row maximum (always on the first tile; otherwise only when the guard trips)
         auto exact = [&]() {
 #pragma unroll
@@ -467,9 +451,6 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
         }
 #pragma unroll
         for (int qi = 0; qi < NQB; qi++) lrun[qi] += ps[qi];
-        TR(3);
-        if (OD_FWD32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-        if (OD_FWD32_PRIO == 1) __builtin_amdgcn_s_setprio(2);
         // O^T += V^T P^T : A = V^T fragment (rows = features of block db), two transpose reads per 16-key slab
 #pragma unroll
         for (int db = 0; db < 2; db++)
@@ -485,10 +466,8 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
 #pragma unroll
                     for (int qi = 0; qi < NQB; qi++) oacc[qi][db] = od_mma32(fv, fp[qi][kb][sl], oacc[qi][db]);
                 }
-        TR(4);
-        if (OD_FWD32_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        OD_WAIT_VMCNT(0);           // this wave's pieces of the next tile have landed (the asm DMA is invisible to hipcc's waits)
         __syncthreads();
-        TR(5);
     };
     // the two LDS stages alternate with compile-time addresses: the loop body is unrolled by two
     unsigned char* const s0 = smem;
@@ -522,42 +501,37 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
     }
 }
 
-// ---- software-pipelined variant: the score MFMAs of tile t+1 are issued under the exponentials of tile t, and the row sums
-// of tile t under its PV MFMAs, so that ONE wave keeps both the matrix pipe and the vector ALU busy (phase_overlap probe:
-// 16 MFMAs then 64 VALU ops as two coarse phases take 904 cycles from one wave, finely interleaved 572).  Two live score tiles
-// (S_cur, S_next).  The overflow guard is delayed by one step: it looks at the partial row sums AFTER the PV MFMAs consumed
-// the tile and rescales O, l, the reference and S_next when a sum left [0, 2^14) — exact, because everything is linear in P
-// as long as no value reached inf (which needs a jump of > 2^113 inside one tile).
-#ifndef OD_FWD32_SGB
-#define OD_FWD32_SGB 1     // sched_group_barrier hints for the MFMA / VALU interleave
-#endif
+// ---- two wave groups in ping-pong (8 waves = 256 queries per workgroup, two waves per SIMD from the SAME workgroup).
+// A SIMD overlaps one wave's MFMA phase with another wave's vector phase completely as long as the vector phase is the shorter
+// one (phase_overlap probe: 16 MFMAs = 512 cycles against 384 cycles of VALU: 511 per pair; against 576 cycles: 862) — but three
+// independent workgroups per CU do not arrange themselves that way (wall = MFMA time + issue time, profiles/r02d_pmc_attn.txt).
+// Here the arrangement is built in: per key tile a wave runs  M(t) = [PV(t-1), QK(t)]  (16 MFMAs, LDS reads, DMA issue) then
+// V(t) = softmax of tile t (exp, row sums, bf16 packing), with a workgroup barrier after each; waves 4-7 lag waves 0-3 by one
+// slot, so on every SIMD an M phase always runs beside a V phase.  K/V tiles sit in a 4-deep LDS ring, streamed two tiles ahead by
+// buffer-addressed LDS-DMA that stays in flight across the (bare) barriers; waits are counted (vmcnt(2)).
 template <bool PRE>
-__global__ __launch_bounds__(256, 2) void flash_fwd32p_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+__global__ __launch_bounds__(512, 1) void flash_fwd32x_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                               const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
                                                               float* __restrict__ lse, int B, int H, int L, float scale) {
-    constexpr int HD = 64, QB = 128, TB = 8192;          // TB = bytes of one 64 x 64 bf16 tile
-    OD_DYN_SMEM(smem);                                   // K0 | K1 | V0 | V1
+    constexpr int HD = 64, QB = 256, TB = 8192, STAGE = 2 * TB;
+    OD_DYN_SMEM(smem);   // 4 stages x (K tile, V tile), swz32
     const int nqt = (L + QB - 1) / QB;
     int qt, bh;
     if (!attn_block_coords(nqt, B * H, qt, bh)) return;
     const int b = bh / H, h = bh % H;
-    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), grp = wave >> 2;
+    const int c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
     const bf16_t* qb_ = q + (size_t)b * L * ldq + h * HD;
     const int q0 = qt * QB + wave * 32;
     const float c = PRE ? 1.f : scale * LOG2E;
     const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
     const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
-    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
+    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);      // wave w streams rows 8w .. 8w+7 of both tiles
     const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
-    auto dmaK = [&](int kt, unsigned char* dst) {
-        const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u;
-        od_buffer_lds16(rk, vk, sk, dst + wave * 1024);
-        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, dst + (wave + 4) * 1024);
-    };
-    auto dmaV = [&](int kt, unsigned char* dst) {
-        const unsigned sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
-        od_buffer_lds16(rv, vv, sv, dst + wave * 1024);
-        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, dst + (wave + 4) * 1024);
+    const unsigned lds0 = od_lds_addr(smem) + wave * 1024;
+    auto dma = [&](int kt, int stage) {
+        od_buffer_lds16_at(rk, vk, (unsigned)kt * 64u * (unsigned)ldk * 2u, lds0 + stage * STAGE);
+        od_buffer_lds16_at(rv, vv, (unsigned)kt * 64u * (unsigned)ldv * 2u, lds0 + stage * STAGE + TB);
     };
     s16x8 fq[4];
     {
@@ -565,156 +539,156 @@ __global__ __launch_bounds__(256, 2) void flash_fwd32p_kernel(const bf16_t* __re
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) fq[s4] = *(const s16x8*)(qb_ + (size_t)row * ldq + s4 * 16 + hi * 8);
     }
-    f32x16_t oacc[2], minit = (f32x16_t)(0.f);
-    oacc[0] = (f32x16_t)(0.f); oacc[1] = (f32x16_t)(0.f);
-    float mref = 0.f, lrun = 0.f;
-    const int nkt = (L + 63) / 64;
-    const bool ragged = (L & 63) != 0;
     int offK[4], offV[2][2];
 #pragma unroll
     for (int s4 = 0; s4 < 4; s4++) offK[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
-        for (int e = 0; e < 2; e++) offV[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+        for (int e = 0; e < 2; e++) offV[db][e] = TB + tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+    f32x16_t oacc[2], minit = (f32x16_t)(0.f), sa[2];
+    oacc[0] = (f32x16_t)(0.f); oacc[1] = (f32x16_t)(0.f);
+    s16x8 fp[2][2];
+    float mref = 0.f, lrun = 0.f;
+    const int nkt = (L + 63) / 64;
+    const bool ragged = (L & 63) != 0;
 
-    unsigned char* const K0 = smem;
-    unsigned char* const K1 = smem + TB;
-    unsigned char* const V0 = smem + 2 * TB;
-    unsigned char* const V1 = smem + 3 * TB;
-
-    auto scores = [&](const unsigned char* tK, int kt, auto mask_t, f32x16_t (&sa)[2]) __attribute__((always_inline)) {
-        s16x8 fk[2][4];
+#if defined(OD_EMU)
+#define OD_PIN() do { } while (0)
+#else
+#define OD_PIN() __builtin_amdgcn_sched_barrier(0)     // pins the phase order: fragment reads ahead of the MFMAs that hide them
+#endif
+    // M(t): DMA of tile t+2, scores of tile t (K fragments were fetched at the end of the previous V phase), PV of tile t-1 (its V
+    // fragments are requested first and arrive under the score MFMAs): the matrix pipe never waits for LDS inside the phase
+    s16x8 fk[2][4];
+    auto load_k = [&](int t) __attribute__((always_inline)) {
+        const unsigned char* stQ = smem + (t & 3) * STAGE;
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) fk[kb][s4] = *(const s16x8*)(tK + offK[s4] + kb * 4096);
+            for (int s4 = 0; s4 < 4; s4++) fk[kb][s4] = *(const s16x8*)(stQ + offK[s4] + kb * 4096);
+    };
+    auto mphase = [&](int t, auto pv_t, auto qk_t) __attribute__((always_inline)) {
+        constexpr bool DO_PV = decltype(pv_t)::value, DO_QK = decltype(qk_t)::value;
+        const unsigned char* stP = smem + ((t + 3) & 3) * STAGE;          // tile t - 1
+        const bool pre = t + 2 < nkt;
+        OD_PIN();
+        if (pre) dma(t + 2, (t + 2) & 3);                                  // tile t + 2 goes where tile t - 2 was
+        OD_PIN();
+        s16x8 fv[2][2][2];
+        if constexpr (DO_PV) {
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
-            sa[kb] = od_mma32(fk[kb][0], fq[0], minit);
+            for (int db = 0; db < 2; db++)
 #pragma unroll
-            for (int s4 = 1; s4 < 4; s4++) sa[kb] = od_mma32(fk[kb][s4], fq[s4], sa[kb]);
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        const s16x4 a0 = od_lds_tr_read((const bf16_t*)(stP + offV[db][0] + (kb * 2 + sl) * 2048));
+                        const s16x4 a1 = od_lds_tr_read((const bf16_t*)(stP + offV[db][1] + (kb * 2 + sl) * 2048));
+                        s16x8& f = fv[db][kb][sl];
+                        f[0] = a0[0]; f[1] = a0[1]; f[2] = a0[2]; f[3] = a0[3];
+                        f[4] = a1[0]; f[5] = a1[1]; f[6] = a1[2]; f[7] = a1[3];
+                    }
+#if !defined(OD_EMU)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
-        if constexpr (!PRE) {
+        if constexpr (DO_QK) {
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) sa[kb] = sa[kb] * c + minit * (1.f - c);
+            for (int kb = 0; kb < 2; kb++) {
+                sa[kb] = od_mma32(fk[kb][0], fq[0], minit);
+#pragma unroll
+                for (int s4 = 1; s4 < 4; s4++) sa[kb] = od_mma32(fk[kb][s4], fq[s4], sa[kb]);
+                if constexpr (!PRE) sa[kb] = sa[kb] * c + minit * (1.f - c);
+            }
+            if (ragged && t + 1 == nkt) {          // wave-uniform: the ragged last tile only
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) sa[kb][r] = NEG_BIG;
+            }
         }
-        if constexpr (decltype(mask_t)::value) {      // the ragged last tile only
+        OD_PIN();
+        if constexpr (DO_PV) {
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) oacc[db] = od_mma32(fv[db][kb][sl], fp[kb][sl], oacc[db]);
+        }
+        OD_PIN();
+        if (pre) OD_WAIT_VMCNT(2); else OD_WAIT_VMCNT(0);     // this wave's pieces of tile t + 1 have landed
+        OD_PIN();
+        od_barrier_raw();
+        OD_PIN();
+    };
+    // V(t): softmax of tile t against the lazy reference; the exact path (first tile, or a partial sum out of range) moves it
+    auto vphase = [&](int t, auto first_t) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_t)::value;
+        auto exact = [&](bool first) {
+            float m = NEG_BIG;
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if (kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) sa[kb][r] = NEG_BIG;
-        }
-    };
-    // move the reference by d (log2 units): O, l and any score tile already computed are rescaled
-    auto shift = [&](float d, f32x16_t (*pending)[2]) __attribute__((always_inline)) {
-        const float alpha = od_exp2(-d);
-        lrun *= alpha;
-        oacc[0] *= alpha; oacc[1] *= alpha;
-        mref += d;
-        minit = (f32x16_t)(-mref);
-        if (pending) { (*pending)[0] -= d; (*pending)[1] -= d; }
-    };
-
-    dmaK(0, K0); dmaV(0, V0);
-    if (nkt > 1) dmaK(1, K1);
-    __syncthreads();
-    f32x16_t sA[2], sB[2];
-    if (nkt == 1 && ragged) scores(K0, 0, std::true_type{}, sA); else scores(K0, 0, std::false_type{}, sA);
-    {   // initial reference: the row maximum of the first tile
-        float m = NEG_BIG;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) m = fmaxf(m, sA[kb][r]);
-        m = fmaxf(m, __shfl_xor(m, 32));
-        mref = m; minit = (f32x16_t)(-m);
-        sA[0] -= m; sA[1] -= m;
-    }
-    // one step: consumes `cur` (tile t), produces `nxt` (tile t + 1) from Kn; V tile t in Vc; DMA targets for V(t+1), K(t+2).
-    // NEXT: 0 = last tile (no successor), 1 = successor, 2 = successor is the ragged last tile; KDMA: tile t + 2 exists.
-    // The hot instance (NEXT = 1, KDMA) has no branch between the score MFMAs, the exponentials and the PV MFMAs: one
-    // scheduling region.
-    auto step = [&](int t, auto next_t, auto kdma_t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2], const unsigned char* Kn, const unsigned char* Vc,
-                    unsigned char* Vdst, unsigned char* Kdst) __attribute__((always_inline)) {
-        constexpr int NEXT = decltype(next_t)::value;
-        if constexpr (NEXT != 0) dmaV(t + 1, Vdst);
-        if constexpr (decltype(kdma_t)::value) dmaK(t + 2, Kdst);
-        // ---- phase A: S_next (MFMA) under p = 2^S_cur (transcendental)
-        if constexpr (NEXT == 1) scores(Kn, t + 1, std::false_type{}, nxt);
-        if constexpr (NEXT == 2) scores(Kn, t + 1, std::true_type{}, nxt);
-        float p[2][16];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) p[kb][r] = od_exp2(cur[kb][r]);
-#if OD_FWD32_SGB && !defined(OD_EMU)
-        if constexpr (NEXT == 1) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // the 8 K fragment reads first
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);  // 4 v_exp
+                for (int r = 0; r < 16; r++) m = fmaxf(m, sa[kb][r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const float d = first ? m : fmaxf(m, 0.f);
+            if (!first) {
+                const float alpha = od_exp2(-d);
+                lrun *= alpha;
+                oacc[0] *= alpha; oacc[1] *= alpha;
             }
-        }
-#endif
-        s16x8 fp[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int sl = 0; sl < 2; sl++) {
-                u32x4 w;
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) w[jj] = od_pack_bf2(p[kb][8 * sl + 2 * jj], p[kb][8 * sl + 2 * jj + 1]);
-                fp[kb][sl] = __builtin_bit_cast(s16x8, w);
-            }
-        // ---- phase B: O^T += V^T P^T (MFMA) under the lane-partial row sums (VALU)
-#pragma unroll
-        for (int db = 0; db < 2; db++)
+            mref += d;
+            minit = (f32x16_t)(-mref);
+            sa[0] -= d; sa[1] -= d;
+        };
+        float ps;
+        auto probs = [&]() {
+            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                 for (int sl = 0; sl < 2; sl++) {
-                    const s16x4 a0 = od_lds_tr_read((const bf16_t*)(Vc + offV[db][0] + (kb * 2 + sl) * 2048));
-                    const s16x4 a1 = od_lds_tr_read((const bf16_t*)(Vc + offV[db][1] + (kb * 2 + sl) * 2048));
-                    s16x8 fv;
-                    fv[0] = a0[0]; fv[1] = a0[1]; fv[2] = a0[2]; fv[3] = a0[3];
-                    fv[4] = a1[0]; fv[5] = a1[1]; fv[6] = a1[2]; fv[7] = a1[3];
-                    oacc[db] = od_mma32(fv, fp[kb][sl], oacc[db]);
+                    u32x4 w;
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const float p0 = od_exp2(sa[kb][8 * sl + 2 * jj]), p1 = od_exp2(sa[kb][8 * sl + 2 * jj + 1]);
+                        a0 += p0; a1 += p1;
+                        w[jj] = od_pack_bf2(p0, p1);
+                    }
+                    fp[kb][sl] = __builtin_bit_cast(s16x8, w);
                 }
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) { a0 += p[kb][r]; a1 += p[kb][r + 1]; a2 += p[kb][r + 2]; a3 += p[kb][r + 3]; }
-        const float ps = (a0 + a1) + (a2 + a3);
-        lrun += ps;
-        if (__any(!(ps < OD_FWD32_GUARD))) {          // wave-uniform, rare: bring the running quantities back into range
-            float d = fmaxf(log2f(fmaxf(ps, 1.f)), 0.f);
-            d = fmaxf(d, __shfl_xor(d, 32));          // one reference per query: both half-waves move together
-            shift(d, NEXT != 0 ? &nxt : nullptr);
+            ps = a0 + a1;
+        };
+        if constexpr (FIRST) { exact(true); probs(); }
+        else {
+            probs();
+            if (__any(!(ps < OD_FWD32_GUARD))) { exact(false); probs(); }
         }
-        __syncthreads();
+        lrun += ps;
+        OD_PIN();
+        if (t + 1 < nkt) load_k(t + 1);      // tile t + 1 was published by the barrier that closed M(t): fetch its K fragments now
+        OD_WAIT_LGKMCNT(0);                  // ... and have them in registers before the M phase, whose transpose reads then need no wait
+        OD_PIN();
+        od_barrier_raw();
+        OD_PIN();
     };
-    // buffers by parity of t: K(t+1) in K[(t+1)&1], V(t) in V[t&1]; DMA V(t+1) -> V[(t+1)&1], K(t+2) -> K[t&1]
-    auto step_at = [&](int t, auto next_t, auto kdma_t) __attribute__((always_inline)) {
-        if (t & 1) step(t, next_t, kdma_t, sB, sA, K0, V1, V0, K1);
-        else step(t, next_t, kdma_t, sA, sB, K1, V0, V1, K0);
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    int t = 0;
-    for (; t + 3 < nkt; t += 2) {                      // both steps have a successor and a tile t + 2 to prefetch
-        step(t, I1{}, std::true_type{}, sA, sB, K1, V0, V1, K0);
-        step(t + 1, I1{}, std::true_type{}, sB, sA, K0, V1, V0, K1);
+    dma(0, 0);
+    if (nkt > 1) dma(1, 1);
+    OD_WAIT_VMCNT(0);
+    od_barrier_raw();
+    if (grp == 1) od_barrier_raw();                    // group B runs one slot behind group A
+    load_k(0);
+    mphase(0, std::false_type{}, std::true_type{});
+    vphase(0, std::true_type{});
+    for (int t = 1; t < nkt; t++) {
+        mphase(t, std::true_type{}, std::true_type{});
+        vphase(t, std::false_type{});
     }
-    for (; t < nkt; t++) {
-        const bool kd = t + 2 < nkt;
-        if (t + 1 >= nkt) step_at(t, I0{}, std::false_type{});
-        else if (t + 2 == nkt && ragged) step_at(t, I2{}, std::false_type{});
-        else if (kd) step_at(t, I1{}, std::true_type{});
-        else step_at(t, I1{}, std::false_type{});
-    }
+    mphase(nkt, std::true_type{}, std::false_type{});   // the closing M phase: PV of the last tile only
+    if (grp == 0) od_barrier_raw();                    // same number of barriers for both groups
     {
         float l = lrun;
         l += __shfl_xor(l, 32);
@@ -1140,7 +1114,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv32_kernel(const bf16_t* _
         if (threadIdx.x < 64) { sl[threadIdx.x] = -r_lse * inv_scale; sl[64 + threadIdx.x] = -r_del; }
     };
     dma(0, smem); gload_small(0); lstore_small(smem);
-    __syncthreads();
+    OD_WAIT_VMCNT(0); __syncthreads();
     const bool kragged = ktile * KB + KB > L;
     const bool kvalid = key0 + c32 < L;
     auto tile = [&](int qt, const unsigned char* st, unsigned char* st_next, auto masked_t) __attribute__((always_inline)) {
@@ -1209,7 +1183,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dkv32_kernel(const bf16_t* _
                     dkacc[db] = od_mma32(fqt, fds[qb][sl], dkacc[db]);
                 }
         if (qt + 1 < nqt) lstore_small(st_next);
-        __syncthreads();
+        OD_WAIT_VMCNT(0); __syncthreads();
     };
     unsigned char* const s0 = smem;
     unsigned char* const s1 = smem + STAGE;
@@ -1289,7 +1263,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq32_kernel(const bf16_t* __
         for (int e = 0; e < 2; e++) offT[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
     const int nkt = (L + 63) / 64;
     dma(0, smem);
-    __syncthreads();
+    OD_WAIT_VMCNT(0); __syncthreads();
     auto tile = [&](int kt, const unsigned char* st, unsigned char* st_next, auto masked_t) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_t)::value;
         if (kt + 1 < nkt) dma(kt + 1, st_next);
@@ -1339,7 +1313,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq32_kernel(const bf16_t* __
                     fkt[0] = a0[0]; fkt[1] = a0[1]; fkt[2] = a0[2]; fkt[3] = a0[3]; fkt[4] = a1[0]; fkt[5] = a1[1]; fkt[6] = a1[2]; fkt[7] = a1[3];
                     dqacc[db] = od_mma32(fkt, fds[kb][sl], dqacc[db]);
                 }
-        __syncthreads();
+        OD_WAIT_VMCNT(0); __syncthreads();
     };
     unsigned char* const s0 = smem;
     unsigned char* const s1 = smem + STAGE;
@@ -1375,9 +1349,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq32_kernel(const bf16_t* __
 template <class T, int HD, bool PRE>
 int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* lse, int B,
                int H, int L, float scale, hipStream_t st) {
-    if constexpr (OD_FWD32 == 2 && std::is_same<T, bf16_t>::value && HD == 64) {
-        const int grid = attn_grid((L + 127) / 128, B * H);
-        OD_LAUNCH_DYN((flash_fwd32p_kernel<PRE>), dim3(grid), dim3(256), (4 * 8192), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+    if constexpr (OD_FWD32 == 4 && std::is_same<T, bf16_t>::value && HD == 64) {
+        const int grid = attn_grid((L + 255) / 256, B * H);
+        OD_LAUNCH_DYN((flash_fwd32x_kernel<PRE>), dim3(grid), dim3(512), (8 * 8192), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
                       (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L, scale);
         OD_CHECK_LAUNCH();
         return 0;

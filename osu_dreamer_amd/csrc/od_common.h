@@ -247,16 +247,52 @@ __device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsig
     emu::global_load_lds16(tmp, (unsigned char*)lds + 16 * emu::lane_id());
 }
 __device__ __forceinline__ int od_uniform(int x) { return x; }
+// the emulator's "LDS address" is an offset from the dynamic shared array
+__device__ __forceinline__ unsigned od_lds_addr(const void* p) { return (unsigned)((const unsigned char*)p - emu::dyn_smem()); }
+__device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
+    od_buffer_lds16(r, voff, soff, emu::dyn_smem() + lds_addr);
+}
 #else
-typedef __amdgpu_buffer_rsrc_t od_srd_t;
+// The DMA is issued from inline asm, on purpose: hipcc treats a builtin LDS-DMA as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the NEXT ds_read of any address (seen in every attention loop: the tile prefetched at the top
+// of an iteration was waited for in the middle of it).  An asm statement is opaque to that pass; the kernels place their own
+// counted waits (OD_WAIT_VMCNT) before the barrier that publishes a tile.  m0 = LDS byte address of lane 0's destination.
+typedef u32x4 od_srd_t;
 __device__ __forceinline__ od_srd_t od_make_srd(const void* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+    const unsigned long long a = (unsigned long long)base;
+    od_srd_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
 }
 __device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsigned soff, void* lds) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds);
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(m0v) : "memory", "m0");
+}
+// same, the destination given as an LDS byte address (od_lds_addr of the array base + offset): no generic-pointer
+// conversion (null check, aperture compare) per call
+__device__ __forceinline__ unsigned od_lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p; }
+__device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(lds_addr) : "memory", "m0");
 }
 // a value the program knows to be wave-uniform, told to the compiler (keeps it in an SGPR)
 __device__ __forceinline__ int od_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+#endif
+
+// Hand-placed synchronisation for kernels that keep LDS-DMA in flight across workgroup barriers: __syncthreads() would drain
+// the VMEM counter (an LDS-DMA is a pending LDS write), so those kernels use a bare s_barrier and counted vmcnt waits.
+#if defined(OD_EMU)
+#define OD_WAIT_VMCNT(n) ((void)0)                       // the emulator's DMA completes at issue
+#define OD_WAIT_LGKMCNT(n) ((void)0)
+__device__ __forceinline__ void od_barrier_raw() { __syncthreads(); }
+#else
+#define OD_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// lgkmcnt(0) through the builtin (simm16: vmcnt = 63, expcnt = 7, lgkmcnt = 0), so that hipcc's own wait insertion SEES it and
+// does not wait again for the same ds_reads at their first use
+#define OD_WAIT_LGKMCNT(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
+__device__ __forceinline__ void od_barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
 #endif
 
 #define OD_CHECK_LAUNCH()                                \

@@ -55,11 +55,14 @@ def test_comm_allreduce_broadcast(pg):
 
 
 def test_ddp_step_world1_equals_plain_step(pg):
+    """Two plain runs of the same two steps differ in the last bits (the weight-gradient GEMMs accumulate with fp32 atomics, and
+    AdamW's first steps turn a sign flip of a near-zero gradient into a 2*lr difference); the run that exchanges its gradients
+    through od_allreduce_grads (world size 1: the mean of one rank) must sit inside that same noise."""
     import bench
     from osu_dreamer_amd.ddp import GradBucketReducer
     dev = torch.device("cuda:0")
     outs = []
-    for ddp in (False, True):
+    for ddp in (False, False, True):
         tr = bench.make_trainer(dev, seed=31)
         tr.diffusion.compute_dtype = torch.bfloat16
         cfg = tr.configure_optimizers()
@@ -81,8 +84,11 @@ def test_ddp_step_world1_equals_plain_step(pg):
         outs.append((float(loss.detach()), tr.diffusion.arena.data.clone(), tr.diffusion_ema.module.arena.data.clone()))
         if red is not None:
             red.close()
-    # weight-gradient GEMMs accumulate with fp32 atomics, so two runs of the SAME step differ in the last bits (and the second
-    # step's bf16 forward amplifies that to ~1e-5 of the loss); the exchange itself must add nothing beyond that
-    assert abs(outs[0][0] - outs[1][0]) <= 2e-4 * abs(outs[0][0])
-    for a, b in ((outs[0][1], outs[1][1]), (outs[0][2], outs[1][2])):
-        assert float((a - b).norm() / b.norm()) < 1e-5
+            tr.diffusion._reducer = None
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    noise_loss = abs(outs[0][0] - outs[1][0]) / abs(outs[0][0])
+    noise_p, noise_e = rel(outs[0][1], outs[1][1]), rel(outs[0][2], outs[1][2])
+    print(f"plain-vs-plain noise: loss {noise_loss:.2e}, params {noise_p:.2e}, ema {noise_e:.2e}; "
+          f"ddp-vs-plain: loss {abs(outs[2][0] - outs[0][0]) / abs(outs[0][0]):.2e}, params {rel(outs[2][1], outs[0][1]):.2e}")
+    assert abs(outs[2][0] - outs[0][0]) <= 3 * noise_loss * abs(outs[0][0]) + 2e-4 * abs(outs[0][0])
+    assert rel(outs[2][1], outs[0][1]) <= 3 * noise_p + 1e-5 and rel(outs[2][2], outs[0][2]) <= 3 * noise_e + 1e-5
