@@ -135,11 +135,14 @@ int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk,
 int od_flash_attn_bwd_passes(void);
 
 /* ---- SwiGLU feed-forward (common/swiglu.py:9-32) ------------------------------------- */
-/* y[b][l][c] = bias[c] + sum_j w[c][j] x[b][l+j-r][c], zero padded.  replaces: swiglu.py:20, model.py:59,62. */
+/* y[b][l][c] = bias[c] + sum_j w[c][j] x[b][l+j-r][c], zero padded; ksize in {3, 5, 7, 9}.  replaces: swiglu.py:20, model.py:59,62. */
 int od_dwconv(int dtype, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int L,
               int C, int ksize, void* stream);
 int od_dwconv_bwd(int dtype, const void* x, int ldx, const float* w, const void* dy, int lddy, void* dx, int lddx,
                   float* dw, float* db, int B, int L, int C, int ksize, void* stream);
+/* x[(b,l)][c] *= scale[b][c] in place (scale fp32 [B][C]): nn.Dropout1d in training mode — the host draws 0 or 1/(1-p) per
+ * (sample, channel); the same call is its backward.  replaces: swiglu.py:23,30. */
+int od_scale_channels(int dtype, void* x, int ldx, const float* scale, int B, int L, int C, void* stream);
 /* hh[m][0:Hp] = rms_norm_Hf(v*silu(g)), v = vg[m][0:Hp], g = vg[m][Hp:2Hp] (columns >= Hf are zero padding).
  * replaces: swiglu.py:28-30. */
 int od_swiglu_rmsnorm(int dtype, const void* vg, int ldvg, void* hh, int ldhh, float* inv_rms, int M, int Hf, int Hp,

@@ -416,10 +416,36 @@ extern "C" int od_silu_bwd(int dtype, const void* x, const void* dy, void* dx, l
     return 0;
 }
 
+// x[(b, l)][c] *= scale[b][c] in place — nn.Dropout1d in training mode (common/swiglu.py:23,30): whole channels of a sample are
+// zeroed with probability p and the survivors scaled by 1 / (1 - p); the host draws the (B, C) factors.  Its own backward.
+template <class T>
+__global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, int ldx, const float* __restrict__ scale, long M, int L, int C) {
+    const int cg = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * cg) return;
+    const long m = i / cg;
+    const int c = (int)(i % cg) * 8;
+    float v[8], f[8];
+    od_ld8(x + m * ldx + c, v);
+    od_ld8(scale + (m / L) * C + c, f);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] *= f[e];
+    od_st8(x + m * ldx + c, v);
+}
+
+extern "C" int od_scale_channels(int dtype, void* x, int ldx, const float* scale, int B, int L, int C, void* stream) {
+    if (C % 8 || ldx % 8) return OD_ERR_ALIGN;
+    const long M = (long)B * L, n = M * (C / 8);
+    if (n == 0) return 0;
+    DISPATCH_T(dtype, OD_LAUNCH((scale_channels_kernel<T_>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (T_*)x, ldx, scale, M, L, C));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int od_dwconv(int dtype, const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int L,
                          int C, int ksize, void* stream) {
     if (C % 8 || ldx % 8 || ldy % 8) return OD_ERR_ALIGN;
-    if (ksize != 3 && ksize != 5) return OD_ERR_UNSUPPORTED;
+    if (ksize != 3 && ksize != 5 && ksize != 7 && ksize != 9) return OD_ERR_UNSUPPORTED;
 #ifndef OD_DW_SMALL_THREADS
 #define OD_DW_SMALL_THREADS 131072      // < 2 workgroups per CU at RUN = 32 (the emulator build lowers it to reach both paths)
 #endif
@@ -429,7 +455,9 @@ extern "C" int od_dwconv(int dtype, const void* x, int ldx, const float* w, cons
     dim3 grid((unsigned)((threads + 255) / 256), B);
 #define DW_GO(KS_, RUN_) DISPATCH_T(dtype, OD_LAUNCH((dwconv_kernel<T_, KS_, RUN_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, bias, (T_*)y, ldy, L, C))
     if (ksize == 5) { if (small) DW_GO(5, 4); else DW_GO(5, 32); }
-    else { if (small) DW_GO(3, 4); else DW_GO(3, 32); }
+    else if (ksize == 3) { if (small) DW_GO(3, 4); else DW_GO(3, 32); }
+    else if (ksize == 7) { if (small) DW_GO(7, 4); else DW_GO(7, 32); }      // radius 3, 4: not a shipped config, same kernel
+    else { if (small) DW_GO(9, 4); else DW_GO(9, 32); }
 #undef DW_GO
     OD_CHECK_LAUNCH();
     return 0;
@@ -443,6 +471,8 @@ extern "C" int od_dwconv_bwd(int dtype, const void* x, int ldx, const float* w, 
     dim3 grid((unsigned)((threads + 255) / 256), B);
     if (ksize == 5) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 5>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
     else if (ksize == 3) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 3>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
+    else if (ksize == 7 && C <= 512) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 7>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
+    else if (ksize == 9 && C <= 512) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 9>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
     else return OD_ERR_UNSUPPORTED;
     OD_CHECK_LAUNCH();
     return 0;

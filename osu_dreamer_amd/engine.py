@@ -63,10 +63,11 @@ class DenoiserEngine:
         self.ksize = 1 + 2 * ba.radius
         self.Hf = int(self.D * ba.expand * 2 / 3)
         self.Hp = _ceil(self.Hf, 64)
-        if ba.radius not in (1, 2):
-            raise NotImplementedError("depthwise kernel sizes 3 and 5 (radius 1, 2) are compiled")
-        if ba.dropout != 0.0:
-            raise NotImplementedError("Dropout1d with p > 0 is not on the compiled path (model.yml uses 0)")
+        if ba.radius not in (0, 1, 2, 3, 4):
+            raise NotImplementedError("depthwise kernel sizes 3, 5, 7, 9 (radius 1-4) are compiled; radius 0 is the identity")
+        if not (0.0 <= ba.dropout < 1.0):
+            raise ValueError(f"dropout probability has to be in [0, 1), got {ba.dropout}")
+        self.dropout = float(ba.dropout)
         self._packed: Dict[str, torch.Tensor] = {}
         self._packed_key = None
         self._plan_key = None
@@ -183,6 +184,7 @@ class DenoiserEngine:
         f32 = torch.float32
         tab = self.ws.t["rope"]
         bcast = self.Ba == 1 and B > 1
+        self.draw_dropout_masks()                             # a fresh channel mask per evaluation, like nn.Dropout1d
         x = self.lbuf("x_in", 0, (M, D))
         ops.proj_in(xt, self.P("proj_in.weight"), self.P("proj_in.bias"), x)
 
@@ -223,12 +225,17 @@ class DenoiserEngine:
             ops.rmsnorm_gate_residual_film(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), ssg2, None, False, h2,
                                            self.lbuf("inv3", i, (M,), f32), B, L)
             # --- feed-forward branch (backbone.py:82-86, swiglu.py:27-32)
-            hdw = self.lbuf("hdw", i, (M, D))
-            ops.dwconv(h2, self.P(p + "ffn.proj_vg.0.weight"), self.P(p + "ffn.proj_vg.0.bias"), hdw, B, L, self.ksize)
+            if self.radius > 0:
+                hdw = self.lbuf("hdw", i, (M, D))
+                ops.dwconv(h2, self.P(p + "ffn.proj_vg.0.weight"), self.P(p + "ffn.proj_vg.0.bias"), hdw, B, L, self.ksize)
+            else:
+                hdw = h2                                      # radius 0: nn.Identity (swiglu.py:20)
             vg = self.lbuf("vg", i, (M, 2 * Hp))
             ops.gemm_nt(hdw, self.W(p + "ffn.proj_vg.1"), self._packed[p + "ffn.proj_vg.1.b"], vg, x3=self.x3)
             hh = self.lbuf("hh", i, (M, Hp))
             ops.swiglu_rmsnorm(vg, hh, self.lbuf("inv4", i, (M,), f32), self.Hf, Hp)
+            if self._drop_active():                           # nn.Dropout1d, training mode only (swiglu.py:23,30)
+                ops.scale_channels(hh, self._drop_mask(i), B, L)
             fo = self.lbuf("fo", i, (M, D))
             ops.gemm_nt(hh, self.W(p + "ffn.proj_o"), self.P(p + "ffn.proj_o.bias"), fo, x3=self.x3)
             # next layer input (at inference x_in.0 / x_in.1 ping-pong), together with the next layer's h1
@@ -254,6 +261,23 @@ class DenoiserEngine:
         dh = self.dh
         ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
                            dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, 1.0 / math.sqrt(self.hd), q_prescaled=True)
+
+    # ---- nn.Dropout1d(p) of the SwiGLU hidden state: a (B, Hp) factor per layer, 0 or 1 / (1 - p), drawn by torch's generator
+    #      (as the reference's mask is) when the module is in training mode; `hh` is stored masked, so proj_o's weight gradient
+    #      sees the dropped activations and the data gradient is masked again on its way back
+    def _drop_active(self) -> bool:
+        return self.dropout > 0.0 and self.model.training
+
+    def _drop_mask(self, i: int) -> torch.Tensor:
+        return self.ws.t[f"drop.{i}"]
+
+    def draw_dropout_masks(self):
+        if not self._drop_active():
+            return
+        keep = 1.0 - self.dropout
+        for i in range(self.depth):
+            m = self.buf(f"drop.{i}", (self.B, self.Hp), torch.float32)
+            m.copy_((torch.rand(self.B, self.Hp, device=m.device) < keep).to(torch.float32) / keep)
 
     def _uhead_w(self, grads=False):
         f = self.G if grads else self.P
@@ -306,14 +330,19 @@ class DenoiserEngine:
             ops.gemm_tn(dbr, t[f"hh.{i}"], self.G(p + "ffn.proj_o.weight"), n_cols=D, k_cols=Hf,
                         dbias=self.G(p + "ffn.proj_o.bias"))
             ops.gemm_nt(dbr, self.W(p + "ffn.proj_o", T=True), None, dhh)
+            if self._drop_active():
+                ops.scale_channels(dhh, self._drop_mask(i), B, L)
             ops.swiglu_rmsnorm_bwd(t[f"vg.{i}"], t[f"inv4.{i}"], dhh, dvg, Hf, Hp)
             gw, gb = self.G(p + "ffn.proj_vg.1.weight"), self.G(p + "ffn.proj_vg.1.bias")
-            hdw = t[f"hdw.{i}"]
+            hdw = t[f"hdw.{i}"] if self.radius > 0 else t[f"h2.{i}"]
             ops.gemm_tn(dvg[:, :Hp], hdw, gw[:Hf], n_cols=Hf, k_cols=D, dbias=gb[:Hf])
             ops.gemm_tn(dvg[:, Hp:], hdw, gw[Hf:], n_cols=Hf, k_cols=D, dbias=gb[Hf:])
-            ops.gemm_nt(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dtmp)
-            ops.dwconv_bwd(t[f"h2.{i}"], self.P(p + "ffn.proj_vg.0.weight"), dtmp, dbr,
-                           self.G(p + "ffn.proj_vg.0.weight"), self.G(p + "ffn.proj_vg.0.bias"), B, L, self.ksize)
+            if self.radius > 0:
+                ops.gemm_nt(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dtmp)
+                ops.dwconv_bwd(t[f"h2.{i}"], self.P(p + "ffn.proj_vg.0.weight"), dtmp, dbr,
+                               self.G(p + "ffn.proj_vg.0.weight"), self.G(p + "ffn.proj_vg.0.bias"), B, L, self.ksize)
+            else:
+                ops.gemm_nt(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dbr)
             ops.rmsnorm_film_bwd(t[f"x_mid.{i}"], t[f"inv3.{i}"], ssg2, dbr, dx, dssg2, B, L)
             # ---- attention branch
             ops.rmsnorm_gate_residual_bwd(t[f"ao.{i}"], t[f"inv2.{i}"], ssg1, dx, dbr, dssg1, B, L)

@@ -107,6 +107,8 @@ class Trainer:
     def validate(self, module, datamodule, device):
         sums: Dict[str, float] = {}
         n = 0
+        was_training = module.training
+        module.eval()                                 # Lightning runs validation in eval mode (Dropout1d off)
         for i, batch in enumerate(datamodule.val_dataloader()):
             if self.limit_val_batches is not None and i >= self.limit_val_batches:
                 break
@@ -115,6 +117,7 @@ class Trainer:
             for k, v in logs.items():
                 sums[k] = sums.get(k, 0.0) + float(v)
             n += 1
+        module.train(was_training)
         return {f"val/{k}": v / max(n, 1) for k, v in sums.items()}
 
     def fit(self, module: DiffusionTrainer, datamodule, ckpt_path: Optional[str] = None):

@@ -300,7 +300,7 @@ class DiffusionModel(nn.Module):
                 steps = tqdm.trange(num_steps)
             except ImportError:
                 pass
-        if self.use_graph and dev.type == "cuda" and num_steps > 1:
+        if self.use_graph and dev.type == "cuda" and num_steps > 1 and not eng._drop_active():     # (a training-mode Dropout1d draws a mask per step)
             # the captured step only references plan-owned buffers (x, u, v, eta, workspace, packed weights), so one
             # instantiated graph serves later calls — as long as those buffers are the SAME allocations: a forward or
             # train step with another shape in between re-plans (new workspace / packed weights), which bumps

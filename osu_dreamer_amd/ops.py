@@ -226,6 +226,13 @@ def dwconv_bwd(x, w, dy, dx, dw, db, B, L, ksize):
                              B, L, C, ksize, _stream(x))
 
 
+def scale_channels(x, scale, B, L):
+    """x[(b, l), c] *= scale[b, c] in place (Dropout1d's channel mask; also its backward)."""
+    _f32(scale)
+    assert scale.shape == (B, x.shape[1]) and scale.is_contiguous()
+    _lib.lib().od_scale_channels(dt_code(x.dtype), _p(x), _ld(x), _p(scale), B, L, x.shape[1], _stream(x))
+
+
 def swiglu_rmsnorm(vg, hh, inv_rms, Hf, Hp, eps=1e-6):
     _f32(inv_rms)
     _lib.lib().od_swiglu_rmsnorm(dt_code(vg.dtype), _p(vg), _ld(vg), _p(hh), _ld(hh), _p(inv_rms), vg.shape[0], Hf, Hp,

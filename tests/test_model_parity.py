@@ -324,3 +324,77 @@ def test_sampler_graph_survives_replanning(dev):
     assert rel_l2(x2, ref) < 1e-4
     # requires_grad survives .to(): the EMA copy stays frozen
     assert not any(p.requires_grad for p in tr.diffusion_ema.module.parameters())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SwiGLU generality (common/swiglu.py:19-23): radius 0 (nn.Identity), wider depthwise kernels, and nn.Dropout1d p > 0
+@pytest.mark.parametrize("radius", [0, 1, 3])
+def test_swiglu_radius_variants_vs_oracle(dev, radius):
+    import dataclasses
+    d = dataclasses.replace(O.TINY, radius=radius)
+    P = O.init_params(d, seed=300 + radius)
+    assert ("net.layers.0.ffn.proj_vg.0.weight" in P) == (radius > 0)
+    data = O.synthetic_batch(d, 2, 37, seed=310 + radius)
+    tr = make_trainer(d, P, dev)
+    dd = {k: v.to(dev) for k, v in data.items()}
+    xt = torch.lerp(data["x0"], data["z"], data["t"][:, None, None])
+    with torch.no_grad():
+        u, v = tr.diffusion(dd["h"], dd["s"], xt.to(dev))
+    ref_u, ref_v = O.forward(data["h"], data["s"], xt, P, d)
+    assert rel_l2(u, ref_u) < 1e-5 and rel_l2(v, ref_v) < 5e-5
+    loss, _ = tr(tr.diffusion, dd["h"], dd["z"], dd["s"], None, t=dd["t"], x0=dd["x0"])
+    loss.backward()
+    ref_loss, _, ref_grads = O.loss_and_grads(P, d, data["h"], data["z"], data["s"], data["t"], data["x0"])
+    assert float(loss.detach()) == pytest.approx(float(ref_loss), rel=5e-5)
+    for k, p in tr.diffusion.named_parameters():
+        assert rel_l2(p.grad, ref_grads[k]) < 1e-3, k
+
+
+def test_dropout1d_training_mode(dev):
+    """nn.Dropout1d(p) on the SwiGLU hidden state: whole channels of a sample dropped, survivors scaled by 1/(1-p), training mode
+    only.  The kernel path (od_scale_channels forward and backward) is compared with the oracle given the SAME channel factors;
+    the factors themselves are checked to be a Dropout1d pattern (per (sample, channel), two values, the right keep rate)."""
+    import dataclasses
+    from osu_dreamer_amd import ops
+    d = O.TINY
+    P = O.init_params(d, seed=320)
+    data = O.synthetic_batch(d, 3, 29, seed=321)
+    tr = DiffusionTrainer(val_batches=2, opt_args=dict(lr=3e-4, weight_decay=0.01),
+                          schedule_args=LRScheduleArgs(warmup_init=.3, warmup_steps=1000, decay_start=30000),
+                          osl_weight=1., del_weight=30., emb_dim=d.emb_dim, a_dim=d.a_dim, style_dim=d.style_dim,
+                          diffusion_args=DiffusionModelArgs(d.global_cond_dim, d.backbone_dim,
+                                                            BackboneArgs(d.depth, d.expand, d.head_dim, d.n_heads, d.radius, dropout=0.25),
+                                                            d.u_head_dim))
+    tr.diffusion.load_state_dict(P)
+    tr = tr.to(dev)
+    m = tr.diffusion
+    dd = {k: v.to(dev) for k, v in data.items()}
+    xt = torch.lerp(data["x0"], data["z"], data["t"][:, None, None]).to(dev)
+    # eval mode: identity
+    m.eval()
+    with torch.no_grad():
+        u0, v0 = m(dd["h"], dd["s"], xt)
+    ref_u, ref_v = O.forward(data["h"], data["s"], xt.cpu(), P, d)
+    assert rel_l2(v0, ref_v) < 5e-5
+    # training mode: masked; replay the drawn factors through the oracle
+    m.train()
+    torch.manual_seed(5)
+    loss, _ = tr(m, dd["h"], dd["z"], dd["s"], None, t=dd["t"], x0=dd["x0"])
+    loss.backward()
+    eng = m.engine
+    masks = [eng.ws.t[f"drop.{i}"].cpu()[:, : eng.Hf].clone() for i in range(d.depth)]
+    for mk in masks:
+        vals = sorted(mk.unique().tolist())
+        assert len(vals) == 2 and vals[0] == 0.0 and vals[1] == pytest.approx(1 / 0.75)
+    keep = float(torch.cat([mk.flatten() for mk in masks]).ne(0).float().mean())
+    assert 0.6 < keep < 0.9
+
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref_loss, _ = O.train_loss(Pg, d, data["h"], data["z"], data["s"], data["t"], data["x0"], drop_scales=masks)
+    ref_loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(ref_loss), rel=5e-5)
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])) < 1e-3, k
+    # and a different draw the next time
+    loss2, _ = tr(m, dd["h"], dd["z"], dd["s"], None, t=dd["t"], x0=dd["x0"])
+    assert not torch.equal(eng.ws.t["drop.0"].cpu()[:, : eng.Hf], masks[0])
