@@ -572,12 +572,24 @@ __device__ __forceinline__ void tn512_frag(od_frag<bf16_t>& f, const unsigned ch
 }
 __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A, int lda,
                                                              float* __restrict__ dW, int lddw, float* __restrict__ dbias,
-                                                             int M, int N, int K, int m_per_block) {
+                                                             int M, int N, int K, int m_per_block, int xcd_order) {
     constexpr int STG = 65536;                 // G slab [64][256] 32 KiB + A slab [64][256] 32 KiB
     OD_DYN_SMEM(smem);
     float* sred = (float*)(smem + 2 * STG);    // 256 floats
     const int tiles_n = (N + 255) / 256, tiles_k = (K + 255) / 256;
-    const int tile = blockIdx.x % (tiles_n * tiles_k), split = blockIdx.x / (tiles_n * tiles_k);
+    int tile, split;
+    if (xcd_order) {
+        // XCD-aware order (block b runs on XCD b % 8): ALL output tiles of one M-split run on one XCD, side by side, so the G / A
+        // row slabs they stream are fetched from HBM once and re-read from that XCD's L2 by the other tiles of the split.  (With
+        // the tile index fastest the tiles of a split were dealt over all 8 XCDs: 3.16 GB of fetches for 1.9 GB of operands on
+        // the qkv shape, profiles/r02j_pmc_step.txt.)  Used when there are many output tiles; with few tiles the extra M-splits it
+        // needs to fill the XCDs cost more in epilogue atomics than the L2 sharing saves (profiles/r02k_ab_gemm_tn_xcd.txt).
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        split = (slot / (tiles_n * tiles_k)) * 8 + xcd;
+        tile = slot % (tiles_n * tiles_k);
+    } else {
+        tile = blockIdx.x % (tiles_n * tiles_k); split = blockIdx.x / (tiles_n * tiles_k);
+    }
     const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
     const int mb = split * m_per_block;
     int me = mb + m_per_block; me = me < M ? me : M;
@@ -719,11 +731,29 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
 #ifndef OD_TN_BLOCKS
 #define OD_TN_BLOCKS 256     // one workgroup per CU: M-splits = 256 / output tiles (fewest fp32 atomics, no second block wave)
 #endif
-            int sp = OD_TN_BLOCKS >= 512 ? (OD_TN_BLOCKS + tiles2 - 1) / tiles2 : (OD_TN_BLOCKS / tiles2 > 0 ? OD_TN_BLOCKS / tiles2 : 1);
+#ifndef OD_TN_XCD_MIN_TILES
+#define OD_TN_XCD_MIN_TILES 16
+#endif
+            const int xcd_order = tiles2 >= OD_TN_XCD_MIN_TILES;
+            int sp, grid_tn;
+            if (xcd_order) {
+                // M-splits = 8 k: each XCD (32 CUs, one workgroup each) holds k splits x tiles2 tiles; pick the k whose k * tiles2 fills
+                // whole waves of 32 workgroups best (qkv: 24 tiles -> k = 4 -> 96 = 3 x 32)
+                int best_k = 1; double best_eff = 0.0;
+                for (int kk = 1; kk <= 8; kk++) {
+                    const int bpx = kk * tiles2, waves = (bpx + 31) / 32;
+                    const double eff = (double)bpx / (waves * 32);
+                    if (eff > best_eff + 1e-9) { best_eff = eff; best_k = kk; }
+                }
+                sp = 8 * best_k;
+            } else {
+                sp = OD_TN_BLOCKS >= 512 ? (OD_TN_BLOCKS + tiles2 - 1) / tiles2 : (OD_TN_BLOCKS / tiles2 > 0 ? OD_TN_BLOCKS / tiles2 : 1);
+            }
             int mpb2 = (M + sp - 1) / sp;
             mpb2 = ((mpb2 + 63) / 64) * 64;
             sp = (M + mpb2 - 1) / mpb2;
-            OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(tiles2 * sp), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2);
+            grid_tn = xcd_order ? ((sp + 7) / 8) * 8 * tiles2 : tiles2 * sp;
+            OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(grid_tn), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order);
             OD_CHECK_LAUNCH();
             return 0;
         }

@@ -53,4 +53,20 @@ if jpath:
     out = {"B": 32, "L": 8192, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --steps 1 --warmup 1 --no-extras (tools/pmc_step.sh); read = 2 x FETCH_SIZE",
            "od_flash_attn_bwd": {"read_bytes": sum(r[3] for r in bwd), "write_bytes": sum(r[4] for r in bwd), "kernels": [r[0] for r in bwd]},
            "od_flash_attn_fwd": {"read_bytes": sum(r[3] for r in fwd), "write_bytes": sum(r[4] for r in fwd), "kernels": [r[0] for r in fwd]}}
+    # kernel classes for the bench line (roofline.also.pmc_classes): time-weighted HBM fraction of the memory-bound kernels,
+    # MFMA-pipe busy fraction of the matrix kernels
+    def klass(n):
+        if "flash_fwd" in n: return "attention_fwd"
+        if "flash_bwd" in n: return "attention_bwd"
+        if "gemm_nt" in n: return "gemm_nt"
+        if "gemm_tn" in n: return "gemm_tn"
+        if any(k in n for k in ("rmsnorm", "swiglu", "qk_norm_rope", "dwconv", "attn_delta", "final_proj", "silu", "adamw", "sqnorm", "cl_to_frames")): return "row_kernels"
+        return "other"
+    agg = defaultdict(lambda: [0.0, 0.0, 0.0])      # time_us, bytes, mfma-busy x time
+    for n, calls, us, rd, wr, mfu, clk in rows:
+        a = agg[klass(n)]
+        a[0] += calls * us; a[1] += calls * (rd + wr); a[2] += calls * us * mfu
+    out["classes"] = {k: {"ms_per_step": round(v[0] / 1e3, 2), "hbm_GBps": round(v[1] / (v[0] * 1e-6) / 1e9, 0) if v[0] else 0,
+                          "hbm_frac_of_8TBps": round(v[1] / (v[0] * 1e-6) / 8e12, 3) if v[0] else 0,
+                          "mfma_busy": round(v[2] / v[0], 3) if v[0] else 0} for k, v in agg.items()}
     json.dump(out, open(jpath, "w"), indent=1)
