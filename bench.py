@@ -97,17 +97,18 @@ def bwd_passes_executed():
     return int(_lib.lib().cdll.od_flash_attn_bwd_passes())
 
 
-def load_traffic(B, L):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of THIS round's kernels (profiles/r02_traffic.json,
-    written by tools/rocpd_pmc.py from separate FETCH_SIZE / WRITE_SIZE rocprofv3 runs: counters cannot be read in-process)."""
+def load_pmc(B, L):
+    """PMC results of THIS round's kernels (profiles/r02_traffic.json, written by tools/pmc_step.sh + tools/pmc_summary.py from
+    separate FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES rocprofv3 passes over one bench step: counters cannot be read
+    in-process).  Returns (HBM bytes per od_flash_attn_bwd launch, per-kernel-class table) or (None, None)."""
     try:
         tr_ = json.load(open(os.path.join(REPO, "profiles", "r02_traffic.json")))
         if (B, L) == (tr_.get("B"), tr_.get("L")):
             e = tr_["od_flash_attn_bwd"]
-            return int(e["read_bytes"] + e["write_bytes"])
+            return int(e["read_bytes"] + e["write_bytes"]), tr_.get("classes")
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def roofline_of_dominant_kernel(tr, B, L):
@@ -132,18 +133,22 @@ def roofline_of_dominant_kernel(tr, B, L):
     unit = 2.0 * B * H * L * L * hd                 # one L x L x hd MFMA pass over all heads
     t_bwd, t_fwd = time_kernel(bwd), time_kernel(fwd)
     executed = bwd_passes_executed()
+    traffic, classes = load_pmc(B, L)
     ach_bwd = BWD_PASSES_ALGORITHMIC * unit / t_bwd / 1e12
     ach_fwd = 2 * unit / t_fwd / 1e12
     return {
         "bound": "mfma", "kernel": "od_flash_attn_bwd (attention backward of one layer)",
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": load_traffic(B, L),
+        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
         "ms_per_launch": round(t_bwd * 1e3, 3),
         "flops_counted": f"algorithmic: {BWD_PASSES_ALGORITHMIC} passes x 2*B*H*L^2*hd",
         "mfma_passes_executed": executed,
         "achieved_executed": round(executed * unit / t_bwd / 1e12, 1),
         "also": {"od_flash_attn_fwd": {"achieved": round(ach_fwd, 1), "frac": round(ach_fwd / PEAK_BF16_TFLOPS, 4),
-                                       "ms_per_launch": round(t_fwd * 1e3, 3)}},
+                                       "ms_per_launch": round(t_fwd * 1e3, 3)},
+                 # per kernel class over one step, from the committed PMC passes (profiles/r02j_pmc_step.txt): HBM fraction of
+                 # 8 TB/s for the memory-bound classes, MFMA-pipe busy fraction for the matrix classes
+                 "pmc_classes": classes},
     }
 
 

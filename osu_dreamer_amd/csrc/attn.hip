@@ -1038,305 +1038,6 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
     }
 }
 
-// ======================================================================== backward, bf16, head_dim 64, 32x32x16 MFMA
-// The two-kernel backward (dK/dV owned by key tiles, dQ by query tiles: no atomics, deterministic) on 32-wide MFMA tiles,
-// with the same trims as the forward: buffer-addressed LDS-DMA (one scalar add per tile), compile-time LDS stage addresses
-// (loops unrolled by two), swz32 tiles that serve both the contiguous and the transposed fragment reads without bank
-// conflicts.  Accumulators start at -lse / -delta (the MFMA's C operand), P = 2^acc, dS' = P * acc'.
-//
-// dK, dV: block = 4 waves x 32 keys; loop over 64-query tiles.
-//   S = Q K^T (rows = queries, cols = keys) ; dP = dO V^T ; dV^T += dO^T P ; dK^T += Q^T dS
-// P / dS accumulators (rows = queries) feed the second pair of MFMAs as B operands through the query permutation
-//   k-slot 8 hi + j of slab sl of query block qb  <->  query 32 qb + 16 sl + 8 (j >> 2) + 4 hi + (j & 3)
-// which the A operands (dO^T, Q^T) reproduce with transpose reads of the row-major tiles.
-template <bool PRE>
-__global__ __launch_bounds__(256, 2) void flash_bwd_dkv32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
-                                                                 const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int lddo,
-                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                 bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv,
-                                                                 int B, int H, int L, float scale) {
-    constexpr int HD = 64, KB = 128, TB = 8192, STAGE = 2 * TB + 512;       // Q tile | dO tile | -lse' (64) | -delta (64)
-    OD_DYN_SMEM(smem);
-    const int nkt = (L + KB - 1) / KB;
-    int ktile, bh;
-    if (!attn_block_coords(nkt, B * H, ktile, bh)) return;
-    const int b = bh / H, h = bh % H;
-    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
-    const bf16_t* kb_ = k + (size_t)b * L * ldk + h * HD;
-    const bf16_t* vb_ = v + (size_t)b * L * ldv + h * HD;
-    const float* lseb = lse + ((size_t)b * H + h) * L;
-    const float* delb = delta + ((size_t)b * H + h) * L;
-    const int key0 = ktile * KB + wave * 32;
-    const float c = scale * LOG2E, inv_scale = PRE ? LOG2E : 1.0f / scale, out_scale = PRE ? LN2 : scale;
-
-    const od_srd_t rq = od_make_srd(q + (size_t)b * L * ldq + h * HD, (unsigned)(((size_t)(L - 1) * ldq + HD) * 2));
-    const od_srd_t rdo = od_make_srd(dout + (size_t)b * L * lddo + h * HD, (unsigned)(((size_t)(L - 1) * lddo + HD) * 2));
-    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
-    const unsigned vq = (unsigned)((wave * 8 + prow) * ldq * 2 + pslot * 16), vdo = (unsigned)((wave * 8 + prow) * lddo * 2 + pslot * 16);
-    auto dma = [&](int qt, unsigned char* st) {
-        const unsigned sq = (unsigned)qt * 64u * (unsigned)ldq * 2u, sd = (unsigned)qt * 64u * (unsigned)lddo * 2u;
-        od_buffer_lds16(rq, vq, sq, st + wave * 1024);
-        od_buffer_lds16(rq, vq, sq + 32u * (unsigned)ldq * 2u, st + (wave + 4) * 1024);
-        od_buffer_lds16(rdo, vdo, sd, st + TB + wave * 1024);
-        od_buffer_lds16(rdo, vdo, sd + 32u * (unsigned)lddo * 2u, st + TB + (wave + 4) * 1024);
-    };
-    // K, V fragments (B operands): column = key, k = 16 s + 8 hi + j
-    s16x8 fk[4], fv[4];
-    {
-        int row = key0 + c32; row = row < L ? row : L - 1;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) {
-            fk[s4] = *(const s16x8*)(kb_ + (size_t)row * ldk + s4 * 16 + hi * 8);
-            fv[s4] = *(const s16x8*)(vb_ + (size_t)row * ldv + s4 * 16 + hi * 8);
-        }
-    }
-    f32x16_t dkacc[2], dvacc[2];
-#pragma unroll
-    for (int db = 0; db < 2; db++) { dkacc[db] = (f32x16_t)(0.f); dvacc[db] = (f32x16_t)(0.f); }
-    int offR[4], offT[2][2];        // contiguous fragment (row c32 (+32), slot 2 s + hi) and transpose-read chunk offsets inside a tile
-#pragma unroll
-    for (int s4 = 0; s4 < 4; s4++) offR[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-        for (int e = 0; e < 2; e++) offT[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
-    const int nqt = (L + 63) / 64;
-    float r_lse = 0.f, r_del = 0.f;
-    auto gload_small = [&](int qt) {
-        if (threadIdx.x < 64) {
-            const int row = qt * 64 + threadIdx.x;
-            r_lse = row < L ? lseb[row] : 0.f;
-            r_del = row < L ? delb[row] : 0.f;
-        }
-    };
-    auto lstore_small = [&](unsigned char* st) {
-        float* sl = (float*)(st + 2 * TB);
-        if (threadIdx.x < 64) { sl[threadIdx.x] = -r_lse * inv_scale; sl[64 + threadIdx.x] = -r_del; }
-    };
-    dma(0, smem); gload_small(0); lstore_small(smem);
-    OD_WAIT_VMCNT(0); __syncthreads();
-    const bool kragged = ktile * KB + KB > L;
-    const bool kvalid = key0 + c32 < L;
-    auto tile = [&](int qt, const unsigned char* st, unsigned char* st_next, auto masked_t) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_t)::value;
-        if (qt + 1 < nqt) { dma(qt + 1, st_next); gload_small(qt + 1); }
-        const unsigned char* tQ = st;
-        const unsigned char* tO = st + TB;
-        const float* s_lse = (const float*)(st + 2 * TB);
-        const float* s_del = s_lse + 64;
-        s16x8 fp[2][2], fds[2][2];
-#pragma unroll
-        for (int qb = 0; qb < 2; qb++) {
-            s16x8 fqr[4], fdo[4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) {
-                fqr[s4] = *(const s16x8*)(tQ + offR[s4] + qb * 4096);
-                fdo[s4] = *(const s16x8*)(tO + offR[s4] + qb * 4096);
-            }
-            f32x16_t sa, pa;       // C operands: element 4 t + i <-> query 32 qb + 8 t + 4 hi + i
-#pragma unroll
-            for (int t4 = 0; t4 < 4; t4++) {
-                const f32x4 l4 = *(const f32x4*)(s_lse + qb * 32 + 8 * t4 + 4 * hi);
-                const f32x4 d4 = *(const f32x4*)(s_del + qb * 32 + 8 * t4 + 4 * hi);
-#pragma unroll
-                for (int i = 0; i < 4; i++) { sa[4 * t4 + i] = l4[i]; pa[4 * t4 + i] = d4[i]; }
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) { sa = od_mma32(fqr[s4], fk[s4], sa); pa = od_mma32(fdo[s4], fv[s4], pa); }
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) p[r] = od_exp2(PRE ? sa[r] : sa[r] * c);
-            if constexpr (MASKED) {
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if (!(kvalid && (qt * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi < L))) p[r] = 0.f;
-            }
-#pragma unroll
-            for (int sl = 0; sl < 2; sl++) {
-                u32x4 wp, wd;
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int r = 8 * sl + 2 * jj;
-                    wp[jj] = od_pack_bf2(p[r], p[r + 1]);
-                    wd[jj] = od_pack_bf2(p[r] * pa[r], p[r + 1] * pa[r + 1]);
-                }
-                fp[qb][sl] = __builtin_bit_cast(s16x8, wp);
-                fds[qb][sl] = __builtin_bit_cast(s16x8, wd);
-            }
-        }
-        // dV^T += dO^T P ; dK^T += Q^T dS   (A rows = features of block db, k = permuted queries, cols = keys)
-#pragma unroll
-        for (int db = 0; db < 2; db++)
-#pragma unroll
-            for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-                for (int sl = 0; sl < 2; sl++) {
-                    const int so = (qb * 2 + sl) * 2048;
-                    const s16x4 o0 = od_lds_tr_read((const bf16_t*)(tO + offT[db][0] + so));
-                    const s16x4 o1 = od_lds_tr_read((const bf16_t*)(tO + offT[db][1] + so));
-                    const s16x4 q0_ = od_lds_tr_read((const bf16_t*)(tQ + offT[db][0] + so));
-                    const s16x4 q1_ = od_lds_tr_read((const bf16_t*)(tQ + offT[db][1] + so));
-                    s16x8 fot, fqt;
-                    fot[0] = o0[0]; fot[1] = o0[1]; fot[2] = o0[2]; fot[3] = o0[3]; fot[4] = o1[0]; fot[5] = o1[1]; fot[6] = o1[2]; fot[7] = o1[3];
-                    fqt[0] = q0_[0]; fqt[1] = q0_[1]; fqt[2] = q0_[2]; fqt[3] = q0_[3]; fqt[4] = q1_[0]; fqt[5] = q1_[1]; fqt[6] = q1_[2]; fqt[7] = q1_[3];
-                    dvacc[db] = od_mma32(fot, fp[qb][sl], dvacc[db]);
-                    dkacc[db] = od_mma32(fqt, fds[qb][sl], dkacc[db]);
-                }
-        if (qt + 1 < nqt) lstore_small(st_next);
-        OD_WAIT_VMCNT(0); __syncthreads();
-    };
-    unsigned char* const s0 = smem;
-    unsigned char* const s1 = smem + STAGE;
-    const int nfull = kragged ? 0 : L / 64;
-    int qt = 0;
-    for (; qt + 1 < nfull; qt += 2) {
-        tile(qt, s0, s1, std::false_type{});
-        tile(qt + 1, s1, s0, std::false_type{});
-    }
-    if (qt < nfull) { tile(qt, s0, s1, std::false_type{}); qt++; }
-    for (; qt < nqt; qt++) { if (qt & 1) tile(qt, s1, s0, std::true_type{}); else tile(qt, s0, s1, std::true_type{}); }
-    const int row = key0 + c32;
-    if (row < L) {
-        bf16_t* dkr = dk + ((size_t)b * L + row) * lddk + h * HD;
-        bf16_t* dvr = dv + ((size_t)b * L + row) * lddv + h * HD;
-#pragma unroll
-        for (int db = 0; db < 2; db++)
-#pragma unroll
-            for (int t4 = 0; t4 < 4; t4++) {
-                st4(dkr + db * 32 + 8 * t4 + 4 * hi, dkacc[db][4 * t4] * out_scale, dkacc[db][4 * t4 + 1] * out_scale, dkacc[db][4 * t4 + 2] * out_scale,
-                    dkacc[db][4 * t4 + 3] * out_scale);
-                st4(dvr + db * 32 + 8 * t4 + 4 * hi, dvacc[db][4 * t4], dvacc[db][4 * t4 + 1], dvacc[db][4 * t4 + 2], dvacc[db][4 * t4 + 3]);
-            }
-    }
-}
-
-// dQ: block = 4 waves x 32 queries; loop over 64-key tiles.
-//   S^T = K Q^T (rows = keys, cols = queries) ; dP^T = V dO^T ; dS^T = P^T * dP^T ; dQ^T += K^T dS^T
-// The query is the accumulator column, so -lse and -delta are per-lane constants of the whole kernel: two splat C operands.
-template <bool PRE>
-__global__ __launch_bounds__(256, 2) void flash_bwd_dq32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
-                                                                const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int lddo,
-                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                bf16_t* __restrict__ dq, int lddq, int B, int H, int L, float scale) {
-    constexpr int HD = 64, QB = 128, TB = 8192, STAGE = 2 * TB;          // K tile | V tile
-    OD_DYN_SMEM(smem);
-    const int nqt = (L + QB - 1) / QB;
-    int qtile, bh;
-    if (!attn_block_coords(nqt, B * H, qtile, bh)) return;
-    const int b = bh / H, h = bh % H;
-    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
-    const bf16_t* qb_ = q + (size_t)b * L * ldq + h * HD;
-    const bf16_t* dob = dout + (size_t)b * L * lddo + h * HD;
-    const int q0 = qtile * QB + wave * 32;
-    const float c = scale * LOG2E, inv_scale = PRE ? LOG2E : 1.0f / scale, out_scale = PRE ? LN2 : scale;
-    const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
-    const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
-    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
-    const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
-    auto dma = [&](int kt, unsigned char* st) {
-        const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u, sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
-        od_buffer_lds16(rk, vk, sk, st + wave * 1024);
-        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
-        od_buffer_lds16(rv, vv, sv, st + TB + wave * 1024);
-        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + TB + (wave + 4) * 1024);
-    };
-    s16x8 fq[4], fdo[4];
-    f32x16_t linit, dinit;
-    {
-        int row = q0 + c32; row = row < L ? row : L - 1;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) {
-            fq[s4] = *(const s16x8*)(qb_ + (size_t)row * ldq + s4 * 16 + hi * 8);
-            fdo[s4] = *(const s16x8*)(dob + (size_t)row * lddo + s4 * 16 + hi * 8);
-        }
-        linit = (f32x16_t)(-lse[((size_t)b * H + h) * L + row] * inv_scale);
-        dinit = (f32x16_t)(-delta[((size_t)b * H + h) * L + row]);
-    }
-    f32x16_t dqacc[2];
-    dqacc[0] = (f32x16_t)(0.f); dqacc[1] = (f32x16_t)(0.f);
-    int offR[4], offT[2][2];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; s4++) offR[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-        for (int e = 0; e < 2; e++) offT[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
-    const int nkt = (L + 63) / 64;
-    dma(0, smem);
-    OD_WAIT_VMCNT(0); __syncthreads();
-    auto tile = [&](int kt, const unsigned char* st, unsigned char* st_next, auto masked_t) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_t)::value;
-        if (kt + 1 < nkt) dma(kt + 1, st_next);
-        const unsigned char* tK = st;
-        const unsigned char* tV = st + TB;
-        s16x8 fds[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
-            s16x8 fkr[4], fvr[4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) {
-                fkr[s4] = *(const s16x8*)(tK + offR[s4] + kb * 4096);
-                fvr[s4] = *(const s16x8*)(tV + offR[s4] + kb * 4096);
-            }
-            f32x16_t sa = od_mma32(fkr[0], fq[0], linit), pa = od_mma32(fvr[0], fdo[0], dinit);
-#pragma unroll
-            for (int s4 = 1; s4 < 4; s4++) { sa = od_mma32(fkr[s4], fq[s4], sa); pa = od_mma32(fvr[s4], fdo[s4], pa); }
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) p[r] = od_exp2(PRE ? sa[r] : sa[r] * c);
-            if constexpr (MASKED) {
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if (kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) p[r] = 0.f;
-            }
-#pragma unroll
-            for (int sl = 0; sl < 2; sl++) {
-                u32x4 wd;
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int r = 8 * sl + 2 * jj;
-                    wd[jj] = od_pack_bf2(p[r] * pa[r], p[r + 1] * pa[r + 1]);
-                }
-                fds[kb][sl] = __builtin_bit_cast(s16x8, wd);
-            }
-        }
-#pragma unroll
-        for (int db = 0; db < 2; db++)
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int sl = 0; sl < 2; sl++) {
-                    const int so = (kb * 2 + sl) * 2048;
-                    const s16x4 a0 = od_lds_tr_read((const bf16_t*)(tK + offT[db][0] + so));
-                    const s16x4 a1 = od_lds_tr_read((const bf16_t*)(tK + offT[db][1] + so));
-                    s16x8 fkt;
-                    fkt[0] = a0[0]; fkt[1] = a0[1]; fkt[2] = a0[2]; fkt[3] = a0[3]; fkt[4] = a1[0]; fkt[5] = a1[1]; fkt[6] = a1[2]; fkt[7] = a1[3];
-                    dqacc[db] = od_mma32(fkt, fds[kb][sl], dqacc[db]);
-                }
-        OD_WAIT_VMCNT(0); __syncthreads();
-    };
-    unsigned char* const s0 = smem;
-    unsigned char* const s1 = smem + STAGE;
-    const int nfull = L / 64;
-    int kt = 0;
-    for (; kt + 1 < nfull; kt += 2) {
-        tile(kt, s0, s1, std::false_type{});
-        tile(kt + 1, s1, s0, std::false_type{});
-    }
-    if (kt < nfull) { tile(kt, s0, s1, std::false_type{}); kt++; }
-    if (kt < nkt) { if (kt & 1) tile(kt, s1, s0, std::true_type{}); else tile(kt, s0, s1, std::true_type{}); }
-    const int row = q0 + c32;
-    if (row < L) {
-        bf16_t* dqr = dq + ((size_t)b * L + row) * lddq + h * HD;
-#pragma unroll
-        for (int db = 0; db < 2; db++)
-#pragma unroll
-            for (int t4 = 0; t4 < 4; t4++)
-                st4(dqr + db * 32 + 8 * t4 + 4 * hi, dqacc[db][4 * t4] * out_scale, dqacc[db][4 * t4 + 1] * out_scale, dqacc[db][4 * t4 + 2] * out_scale,
-                    dqacc[db][4 * t4 + 3] * out_scale);
-    }
-}
-
 #ifndef OD_ATTN_NW
 #define OD_ATTN_NW 4      // waves per workgroup of the bf16 forward / dQ kernels.  6 (K/V streamed once per 192 queries) measured 0.71x: a 6-wave group lands 2,2,1,1 on the SIMDs and a second group no longer fits at 3 waves/SIMD
 #endif
@@ -1382,19 +1083,6 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 #ifndef OD_DKV_NW
 #define OD_DKV_NW 4      // waves per dK/dV workgroup (bf16): 8 = the Q/dO tiles streamed once per 256 keys
 #endif
-#ifndef OD_BWD32
-#define OD_BWD32 0        // 1: the 32x32x16 backward kernels.  Measured 26.3 ms against 25.5 ms for the 16x16x32 pair (profiles/r02e_ab_bwd.txt):
-                          // with P AND dS to convert and four operand tiles to read, the loop's non-MFMA issue time does not shrink with the MFMA count
-#endif
-    if constexpr (OD_BWD32 && std::is_same<T, bf16_t>::value && HD == 64) {
-        const int gk32 = attn_grid((L + 127) / 128, B * H);
-        OD_LAUNCH_DYN((flash_bwd_dkv32_kernel<PRE>), dim3(gk32), dim3(256), (2 * (2 * 8192 + 512)), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                      (const bf16_t*)v, ldv, (const bf16_t*)dout, lddo, lse, (const float*)delta, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, B, H, L, scale);
-        OD_LAUNCH_DYN((flash_bwd_dq32_kernel<PRE>), dim3(gk32), dim3(256), (4 * 8192), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                      (const bf16_t*)v, ldv, (const bf16_t*)dout, lddo, lse, (const float*)delta, (bf16_t*)dq, lddq, B, H, L, scale);
-        OD_CHECK_LAUNCH();
-        return 0;
-    }
     constexpr int NWK = Stage<T, HD>::TR ? OD_DKV_NW : 4;
     const int gk = attn_grid((L + 16 * NWK * NK - 1) / (16 * NWK * NK), B * H);
     OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
