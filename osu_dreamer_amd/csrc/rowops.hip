@@ -8,8 +8,11 @@
 
 namespace {
 
-#ifndef OD_QK_HEAD
-#define OD_QK_HEAD 1
+#ifndef OD_QK_POS
+#define OD_QK_POS 1       // q/k norm + RoPE: the position-major kernel where its shape conditions hold (0 = always the generic kernel)
+#endif
+#ifndef OD_QK_BPW
+#define OD_QK_BPW 8       // batch rows a wave of the position-major kernel handles per position
 #endif
 constexpr int ROWS_PER_WAVE_BWD = 16;  // rows a wave walks in kernels that also reduce over frames
 
@@ -588,128 +591,139 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const T* __restri
     }
 }
 
-// ---- q/k RMSNorm + RoPE, lane-per-head variant (hd = 32 / 64, 2H | 64) -------------------------
-// A lane owns one whole head of one frame (hd contiguous features): the RMS reduction and the rotary
-// pairing (d, d + hd/2) are lane-local — no cross-lane traffic — and a wave moves its 64 heads with
-// hd/8 16-byte loads + stores per lane.  The frame's cos/sin row and the norm weights come from LDS.
-// Fewer, fatter vector-memory instructions per byte than the chunk-per-lane kernel above.
-template <class T, int HD>
-__global__ __launch_bounds__(256) void qk_norm_rope_head_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
-                                                                const float* __restrict__ wk, const float* __restrict__ table,
-                                                                T* __restrict__ out, int ldo, long M, int L, int H, float eps,
-                                                                float q_scale) {
-    constexpr int HALF = HD / 2;
-    __shared__ float s_w[2][HD];
-    __shared__ __attribute__((aligned(16))) float s_tab[64][HD];       // (cos,sin) x HALF per frame of the block
-    const int nslot = 2 * H;                      // head slots per frame (q heads then k heads)
-    const int rpw = 64 / nslot;                   // frames per wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long m0 = (long)blockIdx.x * 4 * rpw;   // first frame of the block
-    for (int i = threadIdx.x; i < 2 * HD; i += 256) s_w[i / HD][i % HD] = (i < HD ? wq[i] : wk[i - HD]);
-    for (int i = threadIdx.x; i < 4 * rpw * HD; i += 256) {
-        const long m = m0 + i / HD;
-        s_tab[i / HD][i % HD] = m < M ? table[(size_t)(m % L) * HD + (i % HD)] : 0.f;
-    }
-    __syncthreads();
-    const int fr = wave * rpw + lane / nslot, slot = lane % nslot;
-    const long m = m0 + fr;
-    if (m >= M) return;
-    const T* src = qkv + m * ldqkv + (size_t)slot * HD;
-    float v[HD];
+// ---- q/k RMSNorm + RoPE, position-major variant (hd = 8*LPH, H*LPH a multiple of 64) -------------------
+// A lane owns 8 consecutive features (one 16-byte piece) and a wave-wide load covers 64 adjacent pieces — 1 KB of one frame, fully
+// coalesced — so a frame's 2H heads take NIT = 2*H*LPH/64 loads.  Because H*LPH is a multiple of 64 the lane's place inside its head
+// (c8 = lane % LPH) is the same in every one of them: its 8 norm weights (q and k) live in registers for the whole kernel, and a wave
+// works on ONE position l for several batch rows (frames b*L + l, b = b0..b1), so the 16 cos/sin values it needs are loaded once per
+// position instead of once per piece.  Cross-lane traffic: the LPH-lane sum of squares and the rotary partner (lane ^ LPH/2).
+// (The lane-per-head kernel this replaces moved whole heads per lane — 64 distinct cache lines per load instruction — and ran at
+// 39 % (backward) / 54 % (forward) of the HBM peak, profiles/r02j_pmc_step.txt.)
+template <class T, int LPH, int NIT>
+__global__ __launch_bounds__(256) void qk_norm_rope_pos_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
+                                                               const float* __restrict__ wk, const float* __restrict__ table,
+                                                               T* __restrict__ out, int ldo, int B, int L, float eps, float q_scale,
+                                                               int bpw, int lpw) {
+    constexpr int HD = 8 * LPH, HALFL = LPH / 2;
+    const int lane = threadIdx.x & 63, c8 = lane % LPH;
+    const int wpl = (B + bpw - 1) / bpw;                          // waves per group of positions
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l0 = (int)(gw / wpl) * lpw, b0 = (int)(gw % wpl) * bpw;
+    if (l0 >= L) return;
+    const int l1 = l0 + lpw < L ? l0 + lpw : L, b1 = b0 + bpw < B ? b0 + bpw : B;
+    float w[2][8];
+    od_ld8(wq + c8 * 8, w[0]); od_ld8(wk + c8 * 8, w[1]);
 #pragma unroll
-    for (int c = 0; c < HD / 8; c++) {
-        float t8[8]; od_ld8(src + c * 8, t8);
+    for (int e = 0; e < 8; e++) w[0][e] *= q_scale;
+    const bool first = c8 < HALFL;
+    for (int l = l0; l < l1; l++) {
+        float tb[16];                                              // (cos, sin) of features j0 .. j0+7 at position l
+        const float* tp = table + ((size_t)l * (HD / 2) + (c8 % HALFL) * 8) * 2;
+        od_ld8(tp, *(float(*)[8])&tb[0]); od_ld8(tp + 8, *(float(*)[8])&tb[8]);
+        float cs[8], sn[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[c * 8 + e] = t8[e];
-    }
-    float ss = 0.f;
+        for (int e = 0; e < 8; e++) { cs[e] = tb[2 * e]; sn[e] = first ? -tb[2 * e + 1] : tb[2 * e + 1]; }
+        for (int b = b0; b < b1; b++) {
+            const long m = (long)b * L + l;
+            float v[NIT][8];
 #pragma unroll
-    for (int d = 0; d < HD; d++) ss += v[d] * v[d];
-    const float inv = rsqrtf(ss / (float)HD + eps);
-    const float* w = s_w[slot < H ? 0 : 1];
-    const float* tb = s_tab[fr];
-    const float invs = inv * (slot < H ? q_scale : 1.f);
-    float o[HD];
+            for (int it = 0; it < NIT; it++) od_ld8(qkv + m * ldqkv + (size_t)(it * 64 + lane) * 8, v[it]);
 #pragma unroll
-    for (int j = 0; j < HALF; j++) {
-        const float y1 = v[j] * invs * w[j], y2 = v[j + HALF] * invs * w[j + HALF];
-        const float cs = tb[2 * j], sn = tb[2 * j + 1];
-        o[j] = y1 * cs - y2 * sn;
-        o[j + HALF] = y1 * sn + y2 * cs;
-    }
-    T* dst = out + m * ldo + (size_t)slot * HD;
+            for (int it = 0; it < NIT; it++) {
+                float ss = 0.f;
 #pragma unroll
-    for (int c = 0; c < HD / 8; c++) {
-        float t8[8];
+                for (int e = 0; e < 8; e++) ss += v[it][e] * v[it][e];
 #pragma unroll
-        for (int e = 0; e < 8; e++) t8[e] = o[c * 8 + e];
-        od_st8(dst + c * 8, t8);
+                for (int msk = 1; msk < LPH; msk <<= 1) ss += __shfl_xor(ss, msk);
+                const float inv = rsqrtf(ss / (float)HD + eps);
+                const float* wv = w[it < NIT / 2 ? 0 : 1];
+                float y[8], o[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) y[e] = v[it][e] * inv * wv[e];
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = y[e] * cs[e] + __shfl_xor(y[e], HALFL) * sn[e];
+                od_st8(out + m * ldo + (size_t)(it * 64 + lane) * 8, o);
+            }
+        }
     }
 }
 
-// backward of the above; a wave walks `iters` frame groups so the per-feature weight gradients
-// accumulate in registers and meet in LDS once per block.
-template <class T, int HD>
-__global__ __launch_bounds__(256) void qk_norm_rope_head_bwd_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
-                                                                    const float* __restrict__ wk, const float* __restrict__ table,
-                                                                    const T* __restrict__ dqk, int lddqk, T* __restrict__ dqkv, int lddqkv,
-                                                                    float* __restrict__ dwq, float* __restrict__ dwk,
-                                                                    long M, int L, int H, float eps, int iters, float q_scale) {
-    constexpr int HALF = HD / 2;
-    __shared__ float s_w[2][HD];
+// backward of the above; the per-feature weight gradients accumulate in registers over the wave's frames, meet across the wave's
+// heads by shuffles and across the block in LDS: 2*HD global atomics per block.
+template <class T, int LPH, int NIT>
+__global__ __launch_bounds__(256) void qk_norm_rope_pos_bwd_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
+                                                                   const float* __restrict__ wk, const float* __restrict__ table,
+                                                                   const T* __restrict__ dqk, int lddqk, T* __restrict__ dqkv, int lddqkv,
+                                                                   float* __restrict__ dwq, float* __restrict__ dwk,
+                                                                   int B, int L, float eps, float q_scale, int bpw, int lpw) {
+    constexpr int HD = 8 * LPH, HALFL = LPH / 2;
     __shared__ float s_dw[2][HD];
-    const int nslot = 2 * H, rpw = 64 / nslot;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2 * HD; i += 256) { s_w[i / HD][i % HD] = (i < HD ? wq[i] : wk[i - HD]); s_dw[i / HD][i % HD] = 0.f; }
+    for (int i = threadIdx.x; i < 2 * HD; i += 256) s_dw[i / HD][i % HD] = 0.f;
     __syncthreads();
-    const int slot = lane % nslot;
-    const float* w = s_w[slot < H ? 0 : 1];
-    const float gs = slot < H ? q_scale : 1.f;        // the forward scaled its q outputs
-    float acc[HD];
+    const int lane = threadIdx.x & 63, c8 = lane % LPH;
+    const int wpl = (B + bpw - 1) / bpw;
+    const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l0 = (int)(gw / wpl) * lpw, b0 = (int)(gw % wpl) * bpw;
+    const int l1 = l0 + lpw < L ? l0 + lpw : L, b1 = b0 + bpw < B ? b0 + bpw : B;
+    float w[2][8], acc[2][8];
+    od_ld8(wq + c8 * 8, w[0]); od_ld8(wk + c8 * 8, w[1]);
 #pragma unroll
-    for (int d = 0; d < HD; d++) acc[d] = 0.f;
-    for (int it = 0; it < iters; it++) {
-        const long m = (((long)blockIdx.x * iters + it) * 4 + wave) * rpw + lane / nslot;
-        if (m >= M) continue;
-        const T* src = qkv + m * ldqkv + (size_t)slot * HD;
-        const T* gsrc = dqk + m * lddqk + (size_t)slot * HD;
-        float v[HD], dy[HD];
+    for (int e = 0; e < 8; e++) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    const bool first = c8 < HALFL;
+    for (int l = l0; l < l1; l++) {                               // (empty when l0 >= L: the wave still joins the barrier below)
+        float tb[16];
+        const float* tp = table + ((size_t)l * (HD / 2) + (c8 % HALFL) * 8) * 2;
+        od_ld8(tp, *(float(*)[8])&tb[0]); od_ld8(tp + 8, *(float(*)[8])&tb[8]);
+        float cs[8], sn[8];
 #pragma unroll
-        for (int c = 0; c < HD / 8; c++) {
-            float t8[8], g8[8]; od_ld8(src + c * 8, t8); od_ld8(gsrc + c * 8, g8);
+        for (int e = 0; e < 8; e++) { cs[e] = tb[2 * e]; sn[e] = first ? tb[2 * e + 1] : -tb[2 * e + 1]; }   // un-rotation
+        for (int b = b0; b < b1; b++) {
+            const long m = (long)b * L + l;
+            float v[NIT][8], d[NIT][8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) { v[c * 8 + e] = t8[e]; dy[c * 8 + e] = g8[e] * gs; }
-        }
-        float ss = 0.f;
+            for (int it = 0; it < NIT; it++) {
+                od_ld8(qkv + m * ldqkv + (size_t)(it * 64 + lane) * 8, v[it]);
+                od_ld8(dqk + m * lddqk + (size_t)(it * 64 + lane) * 8, d[it]);
+            }
 #pragma unroll
-        for (int d = 0; d < HD; d++) ss += v[d] * v[d];
-        const float inv = rsqrtf(ss / (float)HD + eps);
-        const float* tb = table + (size_t)(m % L) * HD;
-        float dot = 0.f;
+            for (int it = 0; it < NIT; it++) {
+                const int qk = it < NIT / 2 ? 0 : 1;
+                const float gs = qk == 0 ? q_scale : 1.f;          // the forward scaled its q outputs
+                float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < HALF; j++) {
-            const float cs = tb[2 * j], sn = tb[2 * j + 1];
-            const float d1 = dy[j] * cs + dy[j + HALF] * sn;          // un-rotate
-            const float d2 = -dy[j] * sn + dy[j + HALF] * cs;
-            const float x1 = v[j] * inv, x2 = v[j + HALF] * inv;
-            acc[j] += d1 * x1; acc[j + HALF] += d2 * x2;
-            const float e1 = d1 * w[j], e2 = d2 * w[j + HALF];
-            dot += e1 * x1 + e2 * x2;
-            dy[j] = e1; dy[j + HALF] = e2; v[j] = x1; v[j + HALF] = x2;
-        }
-        dot /= (float)HD;
-        T* dst = dqkv + m * lddqkv + (size_t)slot * HD;
+                for (int e = 0; e < 8; e++) ss += v[it][e] * v[it][e];
 #pragma unroll
-        for (int c = 0; c < HD / 8; c++) {
-            float t8[8];
+                for (int msk = 1; msk < LPH; msk <<= 1) ss += __shfl_xor(ss, msk);
+                const float inv = rsqrtf(ss / (float)HD + eps);
+                float dy[8], xh[8], dot = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; e++) t8[e] = inv * (dy[c * 8 + e] - v[c * 8 + e] * dot);
-            od_st8(dst + c * 8, t8);
+                for (int e = 0; e < 8; e++) d[it][e] *= gs;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float u = d[it][e] * cs[e] + __shfl_xor(d[it][e], HALFL) * sn[e];
+                    xh[e] = v[it][e] * inv;
+                    acc[qk][e] += u * xh[e];
+                    dy[e] = u * w[qk][e];
+                    dot += dy[e] * xh[e];
+                }
+#pragma unroll
+                for (int msk = 1; msk < LPH; msk <<= 1) dot += __shfl_xor(dot, msk);
+                dot /= (float)HD;
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = inv * (dy[e] - xh[e] * dot);
+                od_st8(dqkv + m * lddqkv + (size_t)(it * 64 + lane) * 8, o);
+            }
         }
     }
-    float* sd = s_dw[slot < H ? 0 : 1];
 #pragma unroll
-    for (int d = 0; d < HD; d++) atomicAdd(&sd[d], acc[d]);
+    for (int msk = LPH; msk < 64; msk <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { acc[0][e] += __shfl_xor(acc[0][e], msk); acc[1][e] += __shfl_xor(acc[1][e], msk); }
+    if (lane < LPH) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { atomicAdd(&s_dw[0][c8 * 8 + e], acc[0][e]); atomicAdd(&s_dw[1][c8 * 8 + e], acc[1][e]); }
+    }
     __syncthreads();
     if (threadIdx.x < HD) { atomicAdd(dwq + threadIdx.x, s_dw[0][threadIdx.x]); atomicAdd(dwk + threadIdx.x, s_dw[1][threadIdx.x]); }
 }
@@ -731,6 +745,14 @@ __global__ void rope_table_kernel(float* __restrict__ table, int L, int hd) {
 }
 
 inline int nch_for(int C) { return (C + 511) / 512; }
+
+// position-major q/k kernels: a wave takes `bpw` batch rows of `lpw` consecutive positions (about 8 frames per wave)
+inline void qk_pos_split(int B, int L, int& bpw, int& lpw) {
+    bpw = B < OD_QK_BPW ? B : OD_QK_BPW;
+    lpw = OD_QK_BPW / bpw;
+    if (lpw < 1) lpw = 1;
+    (void)L;
+}
 
 }  // namespace
 
@@ -874,15 +896,22 @@ extern "C" int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const floa
     if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
     if (ldqkv % 8 || ldo % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
-    if (OD_QK_HEAD && (hd == 64 || hd == 32) && 64 % (2 * H) == 0 && H >= 2) {       // lane-per-head kernel (its LDS table holds 64 frames per block: 4 * 64/(2H) <= 64)
-        const int rpw = 64 / (2 * H);
-        dim3 g2((unsigned)((M + 4 * rpw - 1) / (4 * rpw)));
-#define QKH(TT, HDV) OD_LAUNCH((qk_norm_rope_head_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (TT*)qk_out, ldo, M, L, H, eps, q_scale)
-        if (dtype == OD_BF16) { if (hd == 64) QKH(bf16_t, 64); else QKH(bf16_t, 32); }
-        else { if (hd == 64) QKH(float, 64); else QKH(float, 32); }
-#undef QKH
-        OD_CHECK_LAUNCH();
-        return 0;
+    const int lph = hd / 8;
+    if (OD_QK_POS && (lph == 4 || lph == 8) && (H * lph) % 64 == 0 && ldqkv >= 2 * H * hd) {      // position-major kernel
+        const int nit = 2 * H * lph / 64;
+        if (nit == 2 || nit == 4 || nit == 8) {
+            int bpw, lpw; qk_pos_split(B, L, bpw, lpw);
+            const long waves = (long)((L + lpw - 1) / lpw) * ((B + bpw - 1) / bpw);
+            dim3 g2((unsigned)((waves + 3) / 4));
+#define QKP(TT, LPHV, NITV) OD_LAUNCH((qk_norm_rope_pos_kernel<TT, LPHV, NITV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (TT*)qk_out, ldo, B, L, eps, q_scale, bpw, lpw)
+#define QKP_T(TT) do { if (lph == 8) { if (nit == 2) QKP(TT, 8, 2); else if (nit == 4) QKP(TT, 8, 4); else QKP(TT, 8, 8); } \
+                       else { if (nit == 2) QKP(TT, 4, 2); else if (nit == 4) QKP(TT, 4, 4); else QKP(TT, 4, 8); } } while (0)
+            if (dtype == OD_BF16) QKP_T(bf16_t); else QKP_T(float);
+#undef QKP_T
+#undef QKP
+            OD_CHECK_LAUNCH();
+            return 0;
+        }
     }
     dim3 grid((unsigned)((M + 3) / 4));
     if (dtype == OD_BF16)
@@ -901,15 +930,23 @@ extern "C" int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const 
     if (hd % 16 || hd > 256 || 64 % (hd / 8)) return OD_ERR_UNSUPPORTED;
     if (ldqkv % 8 || lddqk % 8 || lddqkv % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
-    if (OD_QK_HEAD && (hd == 64 || hd == 32) && 64 % (2 * H) == 0) {       // lane-per-head kernel
-        const int rpw = 64 / (2 * H), iters = 16;
-        dim3 g2((unsigned)((M + 4L * rpw * iters - 1) / (4L * rpw * iters)));
-#define QKHB(TT, HDV) OD_LAUNCH((qk_norm_rope_head_bwd_kernel<TT, HDV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (const TT*)dqk, lddqk, (TT*)dqkv, lddqkv, dwq, dwk, M, L, H, eps, iters, q_scale)
-        if (dtype == OD_BF16) { if (hd == 64) QKHB(bf16_t, 64); else QKHB(bf16_t, 32); }
-        else { if (hd == 64) QKHB(float, 64); else QKHB(float, 32); }
-#undef QKHB
-        OD_CHECK_LAUNCH();
-        return 0;
+    const int lph = hd / 8;
+    if (OD_QK_POS && (lph == 4 || lph == 8) && (H * lph) % 64 == 0) {      // position-major kernel
+        const int nit = 2 * H * lph / 64;
+        if (nit == 2 || nit == 4 || nit == 8) {
+            int bpw, lpw; qk_pos_split(B, L, bpw, lpw);
+            lpw *= 4;                                              // 4x fewer blocks meeting in the 2*hd global atomics
+            const long waves = (long)((L + lpw - 1) / lpw) * ((B + bpw - 1) / bpw);
+            dim3 g2((unsigned)((waves + 3) / 4));
+#define QKPB(TT, LPHV, NITV) OD_LAUNCH((qk_norm_rope_pos_bwd_kernel<TT, LPHV, NITV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (const TT*)dqk, lddqk, (TT*)dqkv, lddqkv, dwq, dwk, B, L, eps, q_scale, bpw, lpw)
+#define QKPB_T(TT) do { if (lph == 8) { if (nit == 2) QKPB(TT, 8, 2); else if (nit == 4) QKPB(TT, 8, 4); else QKPB(TT, 8, 8); } \
+                        else { if (nit == 2) QKPB(TT, 4, 2); else if (nit == 4) QKPB(TT, 4, 4); else QKPB(TT, 4, 8); } } while (0)
+            if (dtype == OD_BF16) QKPB_T(bf16_t); else QKPB_T(float);
+#undef QKPB_T
+#undef QKPB
+            OD_CHECK_LAUNCH();
+            return 0;
+        }
     }
     dim3 grid((unsigned)((M + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD)));
     if (dtype == OD_BF16)
