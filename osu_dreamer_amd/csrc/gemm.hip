@@ -15,6 +15,9 @@
 
 namespace {
 
+#ifndef OD_GEMM_NT_STORE_MIN_N
+#define OD_GEMM_NT_STORE_MIN_N 1024   // large-M NT kernel: outputs at least this wide are stored non-temporally
+#endif
 #ifndef OD_GEMM_BIG_MIN_M
 #define OD_GEMM_BIG_MIN_M 32768   // rows from which the 256x256 kernels are used
 #endif
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 template <class T, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                              const float* __restrict__ bias, T* __restrict__ C, int ldc,
-                                                             int M, int N, int K, int accumulate) {
+                                                             int M, int N, int K, int accumulate, int nt_store) {
     constexpr int TM = 256, TN = 256;
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int CH = 16 / (int)sizeof(T);
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] += o[e];
             }
-            od_st8(dst, v);
+            if (nt_store) od_st8_nt(dst, v); else od_st8(dst, v);
         }
     }
 }
@@ -699,10 +702,14 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
     if (epi != OD_EPI_QKROPE && dma && M >= OD_GEMM_BIG_MIN_M && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
         const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256;
         const int grid2 = ((tm2 + 7) / 8) * 8 * tn2;
+        // Wide outputs are written with non-temporal stores: the 128 KiB tile bursts of 256 CUs (32 MiB, the size of all L2s) otherwise
+        // evict the W / A lines the next tiles re-read, and this loop is bound by fetch latency x outstanding misses
+        // (profiles/r02l_gemm_fetch_bound.txt): +7..12 % at N = 1024..2816, +2.5 % at 3072; at N = 512 (2 column tiles) it costs 3 %.
+        const int nt_store = !accumulate && N >= OD_GEMM_NT_STORE_MIN_N;
         if (epi == OD_EPI_SILU)
-            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_SILU>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_SILU>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, nt_store);
         else
-            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_NONE>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate);
+            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_NONE>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, nt_store);
         OD_CHECK_LAUNCH();
         return 0;
     }

@@ -115,6 +115,17 @@ __device__ __forceinline__ void od_st8(bf16_t* p, const float (&v)[8]) {
     *(u32x4*)p = r;
 }
 
+// streaming (non-temporal) form: an output that is not read again soon should not evict re-read operands from the L2
+template <class T> __device__ __forceinline__ void od_st8_nt(T* p, const float (&v)[8]) { od_st8(p, v); }
+#if !defined(OD_EMU)
+template <> __device__ __forceinline__ void od_st8_nt<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = od_pack_bf2(v[2 * i], v[2 * i + 1]);
+    __builtin_nontemporal_store(r, (u32x4*)p);
+}
+#endif
+
 __device__ __forceinline__ float od_wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -252,6 +263,7 @@ __device__ __forceinline__ unsigned od_lds_addr(const void* p) { return (unsigne
 __device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
     od_buffer_lds16(r, voff, soff, emu::dyn_smem() + lds_addr);
 }
+__device__ __forceinline__ void od_buffer_lds16_at_nt(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) { od_buffer_lds16_at(r, voff, soff, lds_addr); }
 #else
 // The DMA is issued from inline asm, on purpose: hipcc treats a builtin LDS-DMA as a pending LDS write and puts
 // `s_waitcnt vmcnt(0)` in front of the NEXT ds_read of any address (seen in every attention loop: the tile prefetched at the top
@@ -276,6 +288,11 @@ __device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsig
 __device__ __forceinline__ unsigned od_lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p; }
 __device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(lds_addr) : "memory", "m0");
+}
+// the same with the non-temporal hint: a stream that is read once (or twice, close together) and should not push a re-read
+// operand out of the XCD's L2
+__device__ __forceinline__ void od_buffer_lds16_at_nt(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen nt lds" ::"v"(voff), "s"(r), "s"(soff), "s"(lds_addr) : "memory", "m0");
 }
 // a value the program knows to be wave-uniform, told to the compiler (keeps it in an SGPR)
 __device__ __forceinline__ int od_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

@@ -22,7 +22,7 @@ def mk(shape, g, dev, dtype=torch.float32, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (128, 128, 64), (77, 24, 16), (300, 384, 192)])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (128, 128, 64), (77, 24, 16), (300, 384, 192), (2100, 520, 128)])
 def test_gemm_nt(dev, dtype, M, N, K):
     g = torch.Generator().manual_seed(1)
     A, W, b = mk((M, K), g, dev, dtype), mk((N, K), g, dev, dtype, 0.2), mk((N,), g, dev)
@@ -36,6 +36,30 @@ def test_gemm_nt(dev, dtype, M, N, K):
     C = C0.clone()
     ops.gemm_nt(A, W, None, C, accumulate=True)
     assert rel_l2(C.float(), ref - b.cpu() + C0.float().cpu()) < TOL[dtype]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(40000, 512, 1024), (33001, 1408, 512), (32768, 3072, 128), (70000, 264, 64)])
+def test_gemm_nt_large_m(M, N, K):
+    """The large-M bf16 path (256x256 tiles; outputs >= 1024 wide stored non-temporally): ragged row and column tiles, one to
+    many k stages per tile, bias / SiLU / accumulate epilogues, against torch on the device."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    A, W, b = mk((M, K), g, dev, bf), mk((N, K), g, dev, bf, 0.2), mk((N,), g, dev)
+    C = torch.zeros(M, N, dtype=bf, device=dev)
+    ops.gemm_nt(A, W, b, C)
+    ref = A.float() @ W.float().t() + b
+    assert float((C.float() - ref).norm() / ref.norm()) < TOL[bf]
+    assert float((C.float() - ref).abs().max()) < 0.05 * float(ref.abs().max())          # no stale / missing tile anywhere
+    ops.gemm_nt(A, W, b, C, epilogue=ops.OD_EPI_SILU)
+    assert float((C.float() - torch.nn.functional.silu(ref)).norm() / ref.norm()) < TOL[bf]
+    C0 = mk((M, N), g, dev, bf)
+    C = C0.clone()
+    ops.gemm_nt(A, W, None, C, accumulate=True)
+    ref2 = ref - b + C0.float()
+    assert float((C.float() - ref2).norm() / ref2.norm()) < TOL[bf]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
