@@ -1122,11 +1122,15 @@ extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* 
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
 #define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st
+// Register tiles of the bf16 / hd 64 backward: 16-row tiles per wave.  The loops are bound by LDS traffic (removing the in-loop DMA, i.e.
+// the LDS writes, takes 25.5 -> 20.2 ms; deeper tile rings, fewer non-MFMA instructions and 8-wave workgroups change nothing —
+// profiles/r02l_ab_bwd_lds_bound.txt): every wave reads the whole streamed tile pair row-wise AND transposed per iteration whatever it owns,
+// so owning more rows per wave is the lever.  48 keys (dK/dV, 256 VGPRs) and 64 queries (dQ, 246 VGPRs) are what two waves per SIMD allow.
 #ifndef OD_BWD_NK
-#define OD_BWD_NK 2
+#define OD_BWD_NK 3
 #endif
 #ifndef OD_BWD_NQ
-#define OD_BWD_NQ 2
+#define OD_BWD_NQ 4
 #endif
 #define BWD(TT, HDV, NKV, NQV) (q_prescaled ? launch_bwd<TT, HDV, NKV, NQV, true>(ARGS) : launch_bwd<TT, HDV, NKV, NQV, false>(ARGS))
     if (dtype == OD_BF16 && hd == 64) return BWD(bf16_t, 64, OD_BWD_NK, OD_BWD_NQ);

@@ -264,6 +264,13 @@ __device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, un
     od_buffer_lds16(r, voff, soff, emu::dyn_smem() + lds_addr);
 }
 __device__ __forceinline__ void od_buffer_lds16_at_nt(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) { od_buffer_lds16_at(r, voff, soff, lds_addr); }
+// one dword per lane: lane i's 4 bytes land at lds_addr + 4*i (zero past the end of the buffer)
+__device__ __forceinline__ void od_buffer_lds4_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned v = 0;
+    const unsigned off = voff + soff;
+    if (off + 4 <= r.bytes) memcpy(&v, r.base + off, 4);
+    memcpy(emu::dyn_smem() + lds_addr + 4 * emu::lane_id(), &v, 4);
+}
 #else
 // The DMA is issued from inline asm, on purpose: hipcc treats a builtin LDS-DMA as a pending LDS write and puts
 // `s_waitcnt vmcnt(0)` in front of the NEXT ds_read of any address (seen in every attention loop: the tile prefetched at the top
@@ -289,6 +296,10 @@ __device__ __forceinline__ unsigned od_lds_addr(const void* p) { return (unsigne
 __device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(lds_addr) : "memory", "m0");
 }
+// one dword per lane (64 x 4 B = 256 B per wave): lane i's dword lands at lds_addr + 4*i, zero past the end of the buffer
+__device__ __forceinline__ void od_buffer_lds4_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(lds_addr) : "memory", "m0");
+}
 // the same with the non-temporal hint: a stream that is read once (or twice, close together) and should not push a re-read
 // operand out of the XCD's L2
 __device__ __forceinline__ void od_buffer_lds16_at_nt(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
@@ -303,9 +314,13 @@ __device__ __forceinline__ int od_uniform(int x) { return __builtin_amdgcn_readf
 #if defined(OD_EMU)
 #define OD_WAIT_VMCNT(n) ((void)0)                       // the emulator's DMA completes at issue
 #define OD_WAIT_LGKMCNT(n) ((void)0)
+#define OD_DRAIN_VMEM() ((void)0)
 __device__ __forceinline__ void od_barrier_raw() { __syncthreads(); }
 #else
 #define OD_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// vmcnt(0) through the builtin (simm16: vmcnt = 0, expcnt = 7, lgkmcnt = 15): hipcc's wait insertion SEES it, so compiler-visible
+// global loads issued before a hand-counted DMA loop are not waited for again (with vmcnt(0)) at their first use INSIDE that loop
+#define OD_DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
 // lgkmcnt(0) through the builtin (simm16: vmcnt = 63, expcnt = 7, lgkmcnt = 0), so that hipcc's own wait insertion SEES it and
 // does not wait again for the same ds_reads at their first use
 #define OD_WAIT_LGKMCNT(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
