@@ -1122,10 +1122,10 @@ extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* 
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
 #define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st
-// Register tiles of the bf16 / hd 64 backward: 16-row tiles per wave.  The loops are bound by LDS traffic (removing the in-loop DMA, i.e.
-// the LDS writes, takes 25.5 -> 20.2 ms; deeper tile rings, fewer non-MFMA instructions and 8-wave workgroups change nothing —
-// profiles/r02l_ab_bwd_lds_bound.txt): every wave reads the whole streamed tile pair row-wise AND transposed per iteration whatever it owns,
-// so owning more rows per wave is the lever.  48 keys (dK/dV, 256 VGPRs) and 64 queries (dQ, 246 VGPRs) are what two waves per SIMD allow.
+// Register tiles of the bf16 / hd 64 backward: 16-row tiles per wave.  Per streamed tile every wave pays a fixed budget — its LDS-DMA
+// pieces, the row-wise AND transposed fragment reads of the whole tile pair, the barrier — whatever it owns (removing the in-loop DMA takes
+// 25.5 -> 20.2 ms; deeper tile rings, trimmed loops and 8-wave workgroups change nothing or lose: profiles/r02l_ab_bwd_tile_budget.txt), so
+// owning more rows per wave is the lever.  48 keys (dK/dV, 256 VGPRs) and 64 queries (dQ, 246 VGPRs) are what two waves per SIMD allow.
 #ifndef OD_BWD_NK
 #define OD_BWD_NK 3
 #endif
