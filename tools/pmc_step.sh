@@ -7,6 +7,6 @@ export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set -d $out/p$i -o res -- python3 bench.py --steps 1 --warmup 1 --no-extras > $out/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set -d $out/p$i -o res -- python3 bench.py --steps 1 --warmup 1 --no-extras > $out/p$i.log 2>&1
 done
 python3 tools/pmc_summary.py $(find $out -name "*.db" | sort) --json $out/traffic.json > $out/pmc_step.txt 2>&1
