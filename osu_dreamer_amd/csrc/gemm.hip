@@ -18,6 +18,9 @@ namespace {
 #ifndef OD_GEMM_NT_STORE_MIN_N
 #define OD_GEMM_NT_STORE_MIN_N 1024   // large-M NT kernel: outputs at least this wide are stored non-temporally
 #endif
+#ifndef OD_TN_BIG_MIN_TILES
+#define OD_TN_BIG_MIN_TILES 8   // weight-gradient GEMM: 256x256 output tiles from this many tiles on (fewer: the M-splits' fp32 atomics dominate)
+#endif
 #ifndef OD_GEMM_BIG_MIN_M
 #define OD_GEMM_BIG_MIN_M 32768   // rows from which the 256x256 kernels are used
 #endif
@@ -441,26 +444,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
     if constexpr (TR) {
         // ---- bf16: LDS-DMA of row-major slabs (out-of-range rows / columns read a global zero), MFMA
         //      fragments by transpose reads.  The bias gradient is summed from the staged G slab in LDS.
+        // Buffer-addressed LDS-DMA from inline asm (the builtin form makes hipcc wait vmcnt(0) before the first transpose read of
+        // every slab, serialising the prefetch with the MFMAs — see gemm_tn_big_kernel).  Each wave stages 4 pieces (4 rows x 256 B)
+        // of the G slab and 4 of the A slab; rows past this block's M range read as zero (the descriptors end at row `me`), columns
+        // past N / K inside a row bring in neighbouring data that only reaches outputs the epilogue drops.
+        const int uw = od_uniform(wave);
+        const long availg = (long)(me - mb - 1) * ldg + (N - n0), availa = (long)(me - mb - 1) * lda + (K - k0);
+        const od_srd_t srdg = od_make_srd(G + (size_t)mb * ldg + n0, (unsigned)((availg > 0 ? availg : 0) * 2));
+        const od_srd_t srda = od_make_srd(A + (size_t)mb * lda + k0, (unsigned)((availa > 0 ? availa : 0) * 2));
+        unsigned vg[4], va[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = (uw * 4 + i) * 4 + (lane >> 4);     // row of the 64-row slab
+            const int pos = lane & 15;                         // 16-byte position within the LDS row
+            const int slot = ((((pos >> 1) ^ (r & 7)) << 1) | (pos & 1));   // logical column chunk stored there
+            vg[i] = (unsigned)(r * ldg * 2 + slot * 16);
+            va[i] = (unsigned)(r * lda * 2 + slot * 16);
+        }
+        const unsigned lds_mine = od_lds_addr(smem) + (unsigned)uw * 4096u;
         auto dma = [&](int st, int buf) {
-            unsigned char* sA = smem + buf * STAGE_BYTES;   // G slab [64 m][128 n]
-            unsigned char* sB = sA + 16384;                  // A slab [64 m][128 k]
+            const unsigned dst = lds_mine + (unsigned)buf * STAGE_BYTES;
+            const unsigned sg = (unsigned)st * BR * (unsigned)ldg * 2u, sa = (unsigned)st * BR * (unsigned)lda * 2u;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int piece = wave * 4 + i;              // 1 KiB = 4 rows x 256 B
-                const int r = piece * 4 + (lane >> 4);
-                const int pos = lane & 15;                    // 16-byte position within the LDS row
-                const int slot = ((((pos >> 1) ^ (r & 7)) << 1) | (pos & 1));   // logical column chunk stored there
-                const int cc = slot * CH;
-                const int m = mb + st * BR + r;
-                const bool mv = m < me;
-                const void* gs = (mv && n0 + cc < N) ? (const void*)(G + (size_t)m * ldg + n0 + cc) : (const void*)od_zero16;
-                const void* as = (mv && k0 + cc < K) ? (const void*)(A + (size_t)m * lda + k0 + cc) : (const void*)od_zero16;
-                od_glds16(gs, sA + piece * 1024 + lane * 16);
-                od_glds16(as, sB + piece * 1024 + lane * 16);
+                od_buffer_lds16_at(srdg, vg[i], sg, dst + i * 1024u);
+                od_buffer_lds16_at(srda, va[i], sa, dst + 16384u + i * 1024u);
             }
         };
         float bsum = 0.f;                                    // thread t < 128 owns column n0 + t
         dma(0, 0);
+        OD_WAIT_VMCNT(0);
         __syncthreads();
         const int x = lane & 15, g = lane >> 4;
         for (int st = 0; st < nslab; st++) {
@@ -486,6 +499,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
                 for (int r = 0; r < 32; r++)
                     bsum += od_bf2f(*(const bf16_t*)(sA + tn_off(half * 32 + r, col * 2)));
             }
+            OD_WAIT_VMCNT(0);
             __syncthreads();
         }
         if (do_bias) atomicAdd(&sred[tid & 127], bsum);
@@ -597,7 +611,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
     const int mb = split * m_per_block;
     int me = mb + m_per_block; me = me < M ? me : M;
     if (mb >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = od_uniform(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int x = lane & 15, g = lane >> 4;
     const bool do_bias = dbias != nullptr && (tile % tiles_k) == 0;
@@ -610,26 +624,33 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4)(0.f);
     const int nslab = (me - mb + 63) / 64;
 
-    auto dma = [&](int st, int buf) {
-        unsigned char* base = smem + buf * STG;
+    // Staging by buffer-addressed LDS-DMA issued from inline asm.  (The builtin form made hipcc put `s_waitcnt vmcnt(0)` in front of
+    // the first transpose read of every slab — the prefetch of slab st+1 was waited for before slab st was touched: DMA-only 1076,
+    // MFMA-only 1046, together 658 TF/s on the qkv shape.)  Waves 0-3 stage the G slab, 4-7 the A slab, 8 pieces of 2 rows x 512 B
+    // each; rows past this block's M range and bytes past the operand's end read as zero (the descriptor ends at row `me`); columns
+    // past N / K inside a row bring in neighbouring data that only reaches output rows / columns the epilogue drops.
+    const bool isa = wave >= 4;
+    const int ld = isa ? lda : ldg, c0 = isa ? k0 : n0, width = isa ? K : N;
+    const bf16_t* opnd = (isa ? A : G) + (size_t)mb * ld + c0;
+    const long avail = (long)(me - mb - 1) * ld + (width - c0);           // elements from `opnd` to the end of row me-1
+    const od_srd_t srd = od_make_srd(opnd, (unsigned)((avail > 0 ? avail : 0) * 2));
+    unsigned voff[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int piece = wave * 8 + i;                  // 0..31 G slab, 32..63 A slab; 2 rows per piece
-            const bool isa = piece >= 32;
-            const int r = (piece & 31) * 2 + (lane >> 5);
-            const int pos = lane & 31;                        // 16-byte position within the 512-byte LDS row
-            const int slot = ((((pos >> 1) ^ (r & 15)) << 1) | (pos & 1));
-            const int cc = slot * 8;
-            const int m = mb + st * 64 + r;
-            const bool mv = m < me;
-            const void* src;
-            if (isa) src = (mv && k0 + cc < K) ? (const void*)(A + (size_t)m * lda + k0 + cc) : (const void*)od_zero16;
-            else src = (mv && n0 + cc < N) ? (const void*)(G + (size_t)m * ldg + n0 + cc) : (const void*)od_zero16;
-            od_glds16(src, base + piece * 1024 + lane * 16);
-        }
+    for (int i = 0; i < 8; i++) {
+        const int r = ((wave & 3) * 8 + i) * 2 + (lane >> 5);              // row of the 64-row slab
+        const int pos = lane & 31;                                          // 16-byte position within the 512-byte LDS row
+        const int slot = ((((pos >> 1) ^ (r & 15)) << 1) | (pos & 1));
+        voff[i] = (unsigned)(r * ld * 2 + slot * 16);
+    }
+    const unsigned lds_mine = od_lds_addr(smem) + (unsigned)wave * 8192u;
+    auto dma = [&](int st, int buf) {
+        const unsigned so = (unsigned)st * 64u * (unsigned)ld * 2u, dst = lds_mine + (unsigned)buf * STG;
+#pragma unroll
+        for (int i = 0; i < 8; i++) od_buffer_lds16_at(srd, voff[i], so, dst + i * 1024u);
     };
     float bsum = 0.f;
     dma(0, 0);
+    OD_WAIT_VMCNT(0);
     __syncthreads();
     for (int st = 0; st < nslab; st++) {
         const int buf = st & 1;
@@ -653,6 +674,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
 #pragma unroll 8
             for (int r = 0; r < 32; r++) bsum += od_bf2f(*(const bf16_t*)(sG + tn512_off(half * 32 + r, col * 2)));
         }
+        OD_WAIT_VMCNT(0);
         __syncthreads();
     }
     if (do_bias) atomicAdd(&sred[tid & 255], bsum);
@@ -734,7 +756,7 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
     if constexpr (sizeof(T) == 2) {
         const int tiles2 = ((N + 255) / 256) * ((K + 255) / 256);
         // few output tiles => many M-splits => the fp32 atomics of the epilogue dominate: stay on 128x128 there
-        if (M >= OD_GEMM_BIG_MIN_M && N >= 256 && K >= 256 && (tiles2 >= 10 || OD_GEMM_BIG_MIN_M < 32768)) {
+        if (M >= OD_GEMM_BIG_MIN_M && N >= 256 && K >= 256 && (tiles2 >= OD_TN_BIG_MIN_TILES || OD_GEMM_BIG_MIN_M < 32768)) {
 #ifndef OD_TN_BLOCKS
 #define OD_TN_BLOCKS 256     // one workgroup per CU: M-splits = 256 / output tiles (fewest fp32 atomics, no second block wave)
 #endif
