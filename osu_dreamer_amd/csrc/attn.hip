@@ -364,6 +364,10 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
 #pragma unroll
         for (int e = 0; e < 2; e++)                                                                  // + 16 rows per slab = + 2048 B
             offV[db][e] = St::BYTES + tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+    // The Q fragments above are compiler-visible loads: drain them with a wait hipcc SEES.  Otherwise it waits for them at their
+    // first use INSIDE the loop (vmcnt(3) .. vmcnt(0) before the first score MFMAs of every other tile), and since the tile
+    // DMAs below are asm it cannot count, those waits also drained the four pieces of the NEXT tile just issued.
+    OD_DRAIN_VMEM();
     dma(0, smem);
     OD_WAIT_VMCNT(0);
     __syncthreads();
