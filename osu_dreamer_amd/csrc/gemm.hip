@@ -715,9 +715,13 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
 #endif
     const bool half = ((M + 127) / 128) * tiles_n < OD_GEMM_SMALL_TILES;
 #ifndef OD_GEMM_QUARTER_TILES
-#define OD_GEMM_QUARTER_TILES 0
+#define OD_GEMM_QUARTER_TILES 0      // bf16: 32-row tiles never paid (out 13.0 -> 12.2 us, proj_o 14.6 -> 15.5 us at M = 4460)
 #endif
-    const bool quarter = ((M + 63) / 64) * tiles_n < OD_GEMM_QUARTER_TILES;
+#ifndef OD_GEMM_QUARTER_TILES_F32
+#define OD_GEMM_QUARTER_TILES_F32 600   // fp32 products (fp32-as-3xbf16 measured +-0: left on 64-row tiles) (32-float k slabs: twice the iterations of bf16, one wave per SIMD at 64-row
+                                        // tiles): 32-row tiles put two workgroups on a CU — out 74 -> 60 us, proj_o 100 -> 80 us at M = 4460
+#endif
+    const bool quarter = ((M + 63) / 64) * tiles_n < (std::is_same<T, float>::value ? OD_GEMM_QUARTER_TILES_F32 : OD_GEMM_QUARTER_TILES);
     const int tiles_m = quarter ? (M + 31) / 32 : half ? (M + 63) / 64 : (M + 127) / 128;
     const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const bool dma = (K % (128 / (int)sizeof(T))) == 0;
