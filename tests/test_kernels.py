@@ -170,6 +170,29 @@ def test_gemm_tn_colsum(dev, dtype, M, N, K):
     assert rel_l2(out, Gf.float().cpu()[:, :N].sum(0)) < TOL[dtype]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(40000, 3072, 512), (33001, 1365, 512), (65536, 512, 1365), (32768, 512, 1024), (50001, 136, 512)])
+def test_gemm_tn_large_m(M, N, K):
+    """The weight-gradient GEMMs at training-size M (256x256 kernel from 8 output tiles on, 128x128 below; both stage their slabs
+    by buffer-addressed asm LDS-DMA whose descriptor ends at the workgroup's last row): ragged M / N / K, operands that are
+    column sub-views of wider buffers holding non-zero neighbours, accumulation into a non-zero dW, the fused bias gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    ldg, lda = (N + 7) // 8 * 8 + 64, (K + 7) // 8 * 8 + 8
+    Gf, Af = mk((M, ldg), g, dev, bf), mk((M, lda), g, dev, bf)
+    Gv, Av = Gf[:, 8:], Af[:, 8:]                         # 16-byte-aligned column sub-views: live data on both sides
+    dW0 = mk((N, K), g, dev)
+    dW, db = dW0.clone(), torch.ones(N, device=dev)
+    ops.gemm_tn(Gv, Av, dW, n_cols=N, k_cols=K, dbias=db)
+    ref = Gv.float()[:, :N].t() @ Av.float()[:, :K] + dW0
+    assert float((dW - ref).norm() / ref.norm()) < 1e-3
+    assert float((dW - ref).abs().max()) < 0.02 * float(ref.abs().max())       # no missing / doubled slab anywhere
+    cs = Gv.float()[:, :N].sum(0)
+    assert float((db - 1 - cs).norm() / cs.norm()) < 1e-3
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_pack_weight(dev, dtype):
     g = torch.Generator().manual_seed(3)
