@@ -505,213 +505,9 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
     }
 }
 
-// ---- two wave groups in ping-pong (8 waves = 256 queries per workgroup, two waves per SIMD from the SAME workgroup).
-// A SIMD overlaps one wave's MFMA phase with another wave's vector phase completely as long as the vector phase is the shorter
-// one (phase_overlap probe: 16 MFMAs = 512 cycles against 384 cycles of VALU: 511 per pair; against 576 cycles: 862) — but three
-// independent workgroups per CU do not arrange themselves that way (wall = MFMA time + issue time, profiles/r02d_pmc_attn.txt).
-// Here the arrangement is built in: per key tile a wave runs  M(t) = [PV(t-1), QK(t)]  (16 MFMAs, LDS reads, DMA issue) then
-// V(t) = softmax of tile t (exp, row sums, bf16 packing), with a workgroup barrier after each; waves 4-7 lag waves 0-3 by one
-// slot, so on every SIMD an M phase always runs beside a V phase.  K/V tiles sit in a 4-deep LDS ring, streamed two tiles ahead by
-// buffer-addressed LDS-DMA that stays in flight across the (bare) barriers; waits are counted (vmcnt(2)).
-template <bool PRE>
-__global__ __launch_bounds__(512, 1) void flash_fwd32x_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
-                                                              const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
-                                                              float* __restrict__ lse, int B, int H, int L, float scale) {
-    constexpr int HD = 64, QB = 256, TB = 8192, STAGE = 2 * TB;
-    OD_DYN_SMEM(smem);   // 4 stages x (K tile, V tile), swz32
-    const int nqt = (L + QB - 1) / QB;
-    int qt, bh;
-    if (!attn_block_coords(nqt, B * H, qt, bh)) return;
-    const int b = bh / H, h = bh % H;
-    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), grp = wave >> 2;
-    const int c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
-    const bf16_t* qb_ = q + (size_t)b * L * ldq + h * HD;
-    const int q0 = qt * QB + wave * 32;
-    const float c = PRE ? 1.f : scale * LOG2E;
-    const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
-    const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
-    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);      // wave w streams rows 8w .. 8w+7 of both tiles
-    const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
-    const unsigned lds0 = od_lds_addr(smem) + wave * 1024;
-    auto dma = [&](int kt, int stage) {
-        od_buffer_lds16_at(rk, vk, (unsigned)kt * 64u * (unsigned)ldk * 2u, lds0 + stage * STAGE);
-        od_buffer_lds16_at(rv, vv, (unsigned)kt * 64u * (unsigned)ldv * 2u, lds0 + stage * STAGE + TB);
-    };
-    s16x8 fq[4];
-    {
-        int row = q0 + c32; row = row < L ? row : L - 1;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) fq[s4] = *(const s16x8*)(qb_ + (size_t)row * ldq + s4 * 16 + hi * 8);
-    }
-    int offK[4], offV[2][2];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; s4++) offK[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-        for (int e = 0; e < 2; e++) offV[db][e] = TB + tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
-    f32x16_t oacc[2], minit = (f32x16_t)(0.f), sa[2];
-    oacc[0] = (f32x16_t)(0.f); oacc[1] = (f32x16_t)(0.f);
-    s16x8 fp[2][2];
-    float mref = 0.f, lrun = 0.f;
-    const int nkt = (L + 63) / 64;
-    const bool ragged = (L & 63) != 0;
+// (An 8-wave ping-pong arrangement of this kernel — two wave groups alternating MFMA and softmax phases behind bare barriers, K/V in a
+// 4-deep LDS ring — measured 8.36 ms against 7.9-8.1 and was removed: profiles/r02g_ab_pingpong.txt.)
 
-#if defined(OD_EMU)
-#define OD_PIN() do { } while (0)
-#else
-#define OD_PIN() __builtin_amdgcn_sched_barrier(0)     // pins the phase order: fragment reads ahead of the MFMAs that hide them
-#endif
-    // M(t): DMA of tile t+2, scores of tile t (K fragments were fetched at the end of the previous V phase), PV of tile t-1 (its V
-    // fragments are requested first and arrive under the score MFMAs): the matrix pipe never waits for LDS inside the phase
-    s16x8 fk[2][4];
-    auto load_k = [&](int t) __attribute__((always_inline)) {
-        const unsigned char* stQ = smem + (t & 3) * STAGE;
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) fk[kb][s4] = *(const s16x8*)(stQ + offK[s4] + kb * 4096);
-    };
-    auto mphase = [&](int t, auto pv_t, auto qk_t) __attribute__((always_inline)) {
-        constexpr bool DO_PV = decltype(pv_t)::value, DO_QK = decltype(qk_t)::value;
-        const unsigned char* stP = smem + ((t + 3) & 3) * STAGE;          // tile t - 1
-        const bool pre = t + 2 < nkt;
-        OD_PIN();
-        if (pre) dma(t + 2, (t + 2) & 3);                                  // tile t + 2 goes where tile t - 2 was
-        OD_PIN();
-        s16x8 fv[2][2][2];
-        if constexpr (DO_PV) {
-#pragma unroll
-            for (int db = 0; db < 2; db++)
-#pragma unroll
-                for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                    for (int sl = 0; sl < 2; sl++) {
-                        const s16x4 a0 = od_lds_tr_read((const bf16_t*)(stP + offV[db][0] + (kb * 2 + sl) * 2048));
-                        const s16x4 a1 = od_lds_tr_read((const bf16_t*)(stP + offV[db][1] + (kb * 2 + sl) * 2048));
-                        s16x8& f = fv[db][kb][sl];
-                        f[0] = a0[0]; f[1] = a0[1]; f[2] = a0[2]; f[3] = a0[3];
-                        f[4] = a1[0]; f[5] = a1[1]; f[6] = a1[2]; f[7] = a1[3];
-                    }
-#if !defined(OD_EMU)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-        if constexpr (DO_QK) {
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-                sa[kb] = od_mma32(fk[kb][0], fq[0], minit);
-#pragma unroll
-                for (int s4 = 1; s4 < 4; s4++) sa[kb] = od_mma32(fk[kb][s4], fq[s4], sa[kb]);
-                if constexpr (!PRE) sa[kb] = sa[kb] * c + minit * (1.f - c);
-            }
-            if (ragged && t + 1 == nkt) {          // wave-uniform: the ragged last tile only
-#pragma unroll
-                for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) sa[kb][r] = NEG_BIG;
-            }
-        }
-        OD_PIN();
-        if constexpr (DO_PV) {
-#pragma unroll
-            for (int db = 0; db < 2; db++)
-#pragma unroll
-                for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                    for (int sl = 0; sl < 2; sl++) oacc[db] = od_mma32(fv[db][kb][sl], fp[kb][sl], oacc[db]);
-        }
-        OD_PIN();
-        if (pre) OD_WAIT_VMCNT(2); else OD_WAIT_VMCNT(0);     // this wave's pieces of tile t + 1 have landed
-        OD_PIN();
-        od_barrier_raw();
-        OD_PIN();
-    };
-    // V(t): softmax of tile t against the lazy reference; the exact path (first tile, or a partial sum out of range) moves it
-    auto vphase = [&](int t, auto first_t) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first_t)::value;
-        auto exact = [&](bool first) {
-            float m = NEG_BIG;
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) m = fmaxf(m, sa[kb][r]);
-            m = fmaxf(m, __shfl_xor(m, 32));
-            const float d = first ? m : fmaxf(m, 0.f);
-            if (!first) {
-                const float alpha = od_exp2(-d);
-                lrun *= alpha;
-                oacc[0] *= alpha; oacc[1] *= alpha;
-            }
-            mref += d;
-            minit = (f32x16_t)(-mref);
-            sa[0] -= d; sa[1] -= d;
-        };
-        float ps;
-        auto probs = [&]() {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                for (int sl = 0; sl < 2; sl++) {
-                    u32x4 w;
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const float p0 = od_exp2(sa[kb][8 * sl + 2 * jj]), p1 = od_exp2(sa[kb][8 * sl + 2 * jj + 1]);
-                        a0 += p0; a1 += p1;
-                        w[jj] = od_pack_bf2(p0, p1);
-                    }
-                    fp[kb][sl] = __builtin_bit_cast(s16x8, w);
-                }
-            ps = a0 + a1;
-        };
-        if constexpr (FIRST) { exact(true); probs(); }
-        else {
-            probs();
-            if (__any(!(ps < OD_FWD32_GUARD))) { exact(false); probs(); }
-        }
-        lrun += ps;
-        OD_PIN();
-        if (t + 1 < nkt) load_k(t + 1);      // tile t + 1 was published by the barrier that closed M(t): fetch its K fragments now
-        OD_WAIT_LGKMCNT(0);                  // ... and have them in registers before the M phase, whose transpose reads then need no wait
-        OD_PIN();
-        od_barrier_raw();
-        OD_PIN();
-    };
-    dma(0, 0);
-    if (nkt > 1) dma(1, 1);
-    OD_WAIT_VMCNT(0);
-    od_barrier_raw();
-    if (grp == 1) od_barrier_raw();                    // group B runs one slot behind group A
-    load_k(0);
-    mphase(0, std::false_type{}, std::true_type{});
-    vphase(0, std::true_type{});
-    for (int t = 1; t < nkt; t++) {
-        mphase(t, std::true_type{}, std::true_type{});
-        vphase(t, std::false_type{});
-    }
-    mphase(nkt, std::true_type{}, std::false_type{});   // the closing M phase: PV of the last tile only
-    if (grp == 0) od_barrier_raw();                    // same number of barriers for both groups
-    {
-        float l = lrun;
-        l += __shfl_xor(l, 32);
-        const float inv = 1.f / l;
-        const int row = q0 + c32;
-        if (row < L) {
-            bf16_t* orow = o + ((size_t)b * L + row) * ldo + h * HD;
-#pragma unroll
-            for (int db = 0; db < 2; db++)
-#pragma unroll
-                for (int t4 = 0; t4 < 4; t4++)
-                    st4(orow + db * 32 + 8 * t4 + 4 * hi, oacc[db][4 * t4] * inv, oacc[db][4 * t4 + 1] * inv, oacc[db][4 * t4 + 2] * inv,
-                        oacc[db][4 * t4 + 3] * inv);
-            if (hi == 0) lse[((size_t)b * H + h) * L + row] = (mref + log2f(l)) * LN2;
-        }
-    }
-}
-
-// ======================================================================== backward
 // delta[b][h][l] = sum_d dO*O  — one wave per frame row, lanes over (h, d) chunks of 8
 template <class T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, int ldo, const T* __restrict__ dout, int lddo,
@@ -1054,13 +850,6 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
 template <class T, int HD, bool PRE>
 int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* lse, int B,
                int H, int L, float scale, hipStream_t st) {
-    if constexpr (OD_FWD32 == 4 && std::is_same<T, bf16_t>::value && HD == 64) {
-        const int grid = attn_grid((L + 255) / 256, B * H);
-        OD_LAUNCH_DYN((flash_fwd32x_kernel<PRE>), dim3(grid), dim3(512), (8 * 8192), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                      (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L, scale);
-        OD_CHECK_LAUNCH();
-        return 0;
-    }
     if constexpr (OD_FWD32 && std::is_same<T, bf16_t>::value && HD == 64) {
         constexpr int NW = 4, NQB = OD_FWD32_NQB;
         const int grid = attn_grid((L + NW * NQB * 32 - 1) / (NW * NQB * 32), B * H);
