@@ -190,7 +190,7 @@ def test_gemm_tn_large_m(M, N, K):
     assert float((dW - ref).norm() / ref.norm()) < 1e-3
     assert float((dW - ref).abs().max()) < 0.02 * float(ref.abs().max())       # no missing / doubled slab anywhere
     cs = Gv.float()[:, :N].sum(0)
-    assert float((db - 1 - cs).norm() / cs.norm()) < 1e-3
+    assert float((db - 1 - cs).norm() / cs.norm()) < 5e-3      # sums of +-1-sized terms: |sum| ~ sqrt(M), fp32 order-of-summation noise
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
