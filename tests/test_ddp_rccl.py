@@ -92,3 +92,27 @@ def test_ddp_step_world1_equals_plain_step(pg):
           f"ddp-vs-plain: loss {abs(outs[2][0] - outs[0][0]) / abs(outs[0][0]):.2e}, params {rel(outs[2][1], outs[0][1]):.2e}")
     assert abs(outs[2][0] - outs[0][0]) <= 3 * noise_loss * abs(outs[0][0]) + 2e-4 * abs(outs[0][0])
     assert rel(outs[2][1], outs[0][1]) <= 3 * noise_p + 1e-5 and rel(outs[2][2], outs[0][2]) <= 3 * noise_e + 1e-5
+
+
+def test_bench_line_through_the_rccl_path():
+    """`bench.py` as the driver's torchrun starts it at N > 1, on the one GPU the pool has: a 1-rank torchrun job (WORLD_SIZE=1 set by
+    the launcher, so bench does not re-spawn) with OD_FORCE_DDP=1 — NCCL process group, RCCL communicator through the C ABI, state
+    broadcast, bucketed all-reduce overlapped with the backward, barrier + MAX over ranks — must print ONE JSON line carrying the
+    collective block and a finite loss."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OD_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--frames", "1024", "--no-extras"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["collective"]["backend"].startswith("RCCL") and d["collective"]["version"] > 0
+    assert d["final_loss"] == d["final_loss"] and d["value"] > 0
