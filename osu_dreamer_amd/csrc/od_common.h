@@ -122,7 +122,9 @@ template <> __device__ __forceinline__ void od_st8_nt<bf16_t>(bf16_t* p, const f
     u32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; i++) r[i] = od_pack_bf2(v[2 * i], v[2 * i + 1]);
-    __builtin_nontemporal_store(r, (u32x4*)p);
+    // inline asm, not __builtin_nontemporal_store: when a runtime flag selects between this and the plain store, hipcc merges the two
+    // arms into ONE plain store and the hint is lost (seen in the ISA of gemm_nt_big_kernel: no `nt` on any store)
+    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(r) : "memory");
 }
 #endif
 
