@@ -31,11 +31,22 @@ __global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ 
     const long nw = (long)gridDim.x * 4, w0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     for (int c = lane * 8; c < D; c += 512) {
         float wv[8][8], bv[8];
+        od_ld8(bias + c, bv);
+        if (E == 6) {
+            // the lane's 8 x 6 weights are 48 consecutive floats (192 B, 16-byte aligned): six 32-byte loads instead of 48 scalar ones
+            // (at the sampler's size the kernel is this prologue: 17 -> 8 us)
+            float flat[48];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            bv[k] = bias[c + k];
+            for (int q = 0; q < 6; q++) od_ld8(W + (size_t)c * 6 + q * 8, *(float(*)[8])&flat[q * 8]);
 #pragma unroll
-            for (int e = 0; e < 8; e++) wv[k][e] = e < E ? W[(size_t)(c + k) * E + e] : 0.f;
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) wv[k][e] = e < 6 ? flat[k * 6 + e] : 0.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) wv[k][e] = e < E ? W[(size_t)(c + k) * E + e] : 0.f;
         }
         for (long m = w0; m < M; m += nw) {
             const int b = (int)(m / L), l = (int)(m % L);

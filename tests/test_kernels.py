@@ -305,11 +305,11 @@ def test_rmsnorm_film_and_gate(dev, dtype, C, bcast):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H,hd", [(2, 32), (16, 64), (3, 16)])
+@pytest.mark.parametrize("H,hd,B,L", [(2, 32, 2, 19), (16, 64, 2, 19), (3, 16, 2, 19),
+                                      (16, 64, 11, 5), (16, 32, 3, 9), (32, 64, 1, 21)])   # last three: position-major kernels, ragged batch / position groups
 @pytest.mark.parametrize("q_scale", [1.0, 0.18])        # 1: the reference's tensor; scale*log2(e): what the engine feeds attention
-def test_qk_norm_rope(dev, dtype, H, hd, q_scale):
+def test_qk_norm_rope(dev, dtype, H, hd, B, L, q_scale):
     g = torch.Generator().manual_seed(7)
-    B, L = 2, 19
     M, dh = B * L, H * hd
     qkv = mk((M, 3 * dh), g, dev, dtype)
     wq, wk = 1 + .2 * mk((hd,), g, dev), 1 + .2 * mk((hd,), g, dev)
