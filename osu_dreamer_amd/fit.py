@@ -72,7 +72,7 @@ class Trainer:
         self.best_val = float("inf")
         # `devices: N` = N ranks, one per GPU (model.yml:11).  The ranks are started by `fit_denoiser` / the CLI
         # (launch.spawn_ranks_if_needed) before anything touches the GPU; inside a rank WORLD_SIZE must agree.
-        self.devices = int(devices) if not isinstance(devices, (list, tuple)) else len(devices)
+        self.devices = launch.parse_devices(devices)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.devices > 1 and self.world != self.devices:
             raise RuntimeError(f"trainer.devices={self.devices} but WORLD_SIZE={self.world}: start the run through "
@@ -228,8 +228,7 @@ def fit_denoiser(config: str = DEFAULT_CONFIG, ckpt_path: Optional[str] = None, 
         cfg.setdefault(sec, {})[key] = v
     if cfg.get("seed_everything") not in (None, False):
         seed_everything(cfg["seed_everything"])
-    devices = cfg.get("trainer", {}).get("devices", 1)
-    devices = len(devices) if isinstance(devices, (list, tuple)) else int(devices)
+    devices = launch.parse_devices(cfg.get("trainer", {}).get("devices", 1))
     if devices > 1 and launch.world_from_env() is None:
         raise RuntimeError("fit_denoiser(devices > 1) must run inside a rank: use `python -m osu_dreamer_amd fit-denoiser` "
                            "(it starts the ranks) or torchrun")
@@ -248,8 +247,7 @@ def main(argv=None):
     a = ap.parse_args(argv)
     if a.cmd == "fit-denoiser":
         with open(a.config) as fh:
-            devices = (yaml.safe_load(fh).get("trainer") or {}).get("devices", 1)
-        devices = len(devices) if isinstance(devices, (list, tuple)) else int(devices)
+            devices = launch.parse_devices((yaml.safe_load(fh).get("trainer") or {}).get("devices", 1))
         # trainer.devices N > 1: this process only starts the N ranks (children; nothing here has touched the GPU)
         rc = launch.spawn_ranks_if_needed(devices, ["fit-denoiser", "-c", a.config] + (["--ckpt-path", a.ckpt_path] if a.ckpt_path else []),
                                           module="osu_dreamer_amd")

@@ -15,6 +15,17 @@ import sys
 from typing import List, Optional, Sequence
 
 
+def parse_devices(devices) -> int:
+    """`trainer.devices` as Lightning accepts it: an int, a list of device indices, or "auto" / -1 (= every visible GPU; counting
+    devices does not initialise the GPU)."""
+    if isinstance(devices, (list, tuple)):
+        return max(1, len(devices))
+    if devices in ("auto", "-1", -1):
+        import torch
+        return max(1, torch.cuda.device_count())
+    return max(1, int(devices))
+
+
 def world_from_env() -> Optional[int]:
     w = os.environ.get("WORLD_SIZE")
     return int(w) if w is not None else None
