@@ -3,6 +3,7 @@
 //   mode 0: LDS-DMA               buffer_load_dwordx4 ... lds          (what the GEMM / attention kernels use)
 //   mode 1: global_load_dwordx4 -> VGPR -> ds_write_b128               (register staging)
 //   mode 2: global_load_dwordx4 -> VGPR only                            (the load path alone)
+//   mode 3: even waves as mode 0, odd waves as mode 1                   (do the two paths add up?)
 // U pieces are in flight per wave (U = 4, 8, 16).  Piece shape: 16 rows x 64 B at a row stride of LD bytes (GEMM k-slab) or 1 KiB
 // contiguous.  Output: GB/s per CU and for the chip.
 #include <hip/hip_runtime.h>
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(512) void k(const unsigned char* __restrict__ src, 
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t off = (p % npieces) * piece_step + lane_off;
-            if (MODE == 0) {
+            if (MODE == 0 || (MODE == 3 && !(wave & 1))) {
                 const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave + u * 1024), vo = (unsigned)off;
                 const unsigned zero = 0; asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(srd), "s"(zero), "s"(m0v) : "memory", "m0");
             } else {
@@ -41,11 +42,14 @@ __global__ __launch_bounds__(512) void k(const unsigned char* __restrict__ src, 
             }
             p += 8;
         }
-        if (MODE == 0) {
+        if (MODE == 0 || (MODE == 3 && !(wave & 1))) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (MODE == 1) {
+        } else if (MODE == 1 || MODE == 3) {
 #pragma unroll
-            for (int u = 0; u < U; u++) *(u32x4*)(smem + wave * U * 1024 + u * 1024 + lane * 16) = v[u];
+            for (int u = 0; u < U; u++) {                      // asm: a plain store here is dead (overwritten next iteration) and was removed
+                const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + wave * U * 1024 + u * 1024 + lane * 16;
+                asm volatile("ds_write_b128 %0, %1" ::"v"(la), "v"(v[u]) : "memory");
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < U; u++) acc ^= v[u];
@@ -80,11 +84,14 @@ int main() {
     ALL(0, "L2  contiguous 1 KiB     LDS-DMA", src, 0, (size_t)2 << 20, 0, out)
     ALL(1, "L2  contiguous 1 KiB     load + ds_write_b128", src, 0, (size_t)2 << 20, 0, out)
     ALL(2, "L2  contiguous 1 KiB     load only", src, 0, (size_t)2 << 20, 0, out)
+    ALL(3, "L2  contiguous 1 KiB     half DMA, half load + ds_write", src, 0, (size_t)2 << 20, 0, out)
     ALL(0, "L2  16 rows x 64 B / 1 KiB stride   LDS-DMA", src, 0, (size_t)2 << 20, 1024, out)
     ALL(1, "L2  16 rows x 64 B / 1 KiB stride   load + ds_write", src, 0, (size_t)2 << 20, 1024, out)
     ALL(2, "L2  16 rows x 64 B / 1 KiB stride   load only", src, 0, (size_t)2 << 20, 1024, out)
     ALL(0, "L2  16 rows x 64 B / 6 KiB stride   LDS-DMA", src, 0, (size_t)3 << 20, 6144, out)
     ALL(2, "L2  16 rows x 64 B / 6 KiB stride   load only", src, 0, (size_t)3 << 20, 6144, out)
+    ALL(1, "L2  16 rows x 64 B / 6 KiB stride   load + ds_write", src, 0, (size_t)3 << 20, 6144, out)
+    ALL(3, "L2  16 rows x 64 B / 6 KiB stride   half DMA, half load + ds_write", src, 0, (size_t)3 << 20, 6144, out)
     printf("# HBM stream: each CU walks its own 16 MiB\n");
     ALL(0, "HBM contiguous 1 KiB     LDS-DMA", src, (size_t)16 << 20, (size_t)16 << 20, 0, out)
     ALL(1, "HBM contiguous 1 KiB     load + ds_write_b128", src, (size_t)16 << 20, (size_t)16 << 20, 0, out)
