@@ -49,6 +49,12 @@ int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, const 
 int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                       int N, int K, const float* wq, const float* wk, const float* table, int L, int H, int hd, float eps,
                       float q_scale, void* stream);
+/* the training-time form of the above: C[M,N] keeps the pre-norm projection (the backward of the norm needs it) and the normed +
+ * rotated q, k go to qk_out[M, 2*H*hd].  One launch at training sizes (bf16, hd 64, M >= 32768: the norm + RoPE run in the large-M
+ * GEMM's epilogue); otherwise od_gemm_nt followed by od_qk_norm_rope.  replaces: attn.py:74-80. */
+int od_gemm_nt_qkrope_split(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                            void* qk_out, int ldqk, int M, int N, int K, const float* wq, const float* wk, const float* table,
+                            int L, int H, int hd, float eps, float q_scale, void* stream);
 /* dW[N,K] (fp32, ld lddw) += G[M,N]^T A[M,K]; if dbias != NULL also dbias[N] += column sums of G
  * — autograd weight and bias gradients of the above, G read once. */
 int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M, int N,

@@ -88,6 +88,8 @@ __device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int& tm,
 struct RopeEpi {
     const float* wq; const float* wk; const float* table;   // norm weights [hd], (cos, sin) table [L][hd/2][2]
     int L, dh, hd, n_rope; float eps, q_scale;               // dh = H*hd (q columns), n_rope = 2*dh; q outputs * q_scale
+    void* qk_out; int ldqk;                                  // large-M kernel only: normed + rotated q, k go HERE (C keeps the pre-norm
+                                                             // values the backward needs); NULL: they replace C[:, :n_rope]
 };
 constexpr int OD_EPI_QKROPE = 2;
 
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
 template <class T, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                              const float* __restrict__ bias, T* __restrict__ C, int ldc,
-                                                             int M, int N, int K, int accumulate, int nt_store) {
+                                                             int M, int N, int K, int accumulate, int nt_store, RopeEpi rp) {
     constexpr int TM = 256, TN = 256;
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int CH = 16 / (int)sizeof(T);
@@ -364,6 +366,65 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict
                 for (int j = 0; j < 8; j++) acc[i][j] = od_mma(fw[i], fa[j], acc[i][j]);
         }
         __syncthreads();
+    }
+    if constexpr (EPI == OD_EPI_QKROPE) {
+        // q/k RMSNorm + RoPE (attn.py:74-80) on the accumulators.  A wave's 64 columns are ONE head (hd = 64), a lane holds columns
+        // 8g..8g+7 and 32+8g..32+8g+7 of it for row x: the rotary partner (d, d + 32) is in the same lane and the head's sum of
+        // squares needs two shuffles (lanes x, x+16, x+32, x+48).  The pre-norm values are rounded to the tensor type first (what the
+        // unfused path reads back) and, when a second output is given, stored to C for the backward.
+        const int hc0 = n0 + wn * 64;
+        const bool roped = hc0 < rp.n_rope, isq = hc0 < rp.dh;
+        T* qk = (T*)rp.qk_out;
+        float wv[2][8], bv[2][8];
+        {
+            const float* w = isq ? rp.wq : rp.wk;
+            od_ld8(w + 8 * g, wv[0]); od_ld8(w + 32 + 8 * g, wv[1]);
+            const int c0 = hc0 + 8 * g < N ? hc0 + 8 * g : 0, c1 = hc0 + 32 + 8 * g < N ? hc0 + 32 + 8 * g : 0;
+            od_ld8(bias + c0, bv[0]); od_ld8(bias + c1, bv[1]);
+        }
+        const float qs = isq ? rp.q_scale : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int gm = m0 + wm * 128 + j * 16 + x;
+            const bool valid = gm < M && hc0 < N;
+            float v[2][8];
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    v[p][r] = od_round_to<T>(acc[2 * p][j][r] + bv[p][r]);
+                    v[p][4 + r] = od_round_to<T>(acc[2 * p + 1][j][r] + bv[p][4 + r]);
+                }
+            T* crow = C + (size_t)(valid ? gm : 0) * ldc + hc0 + 8 * g;
+            if (!roped || qk) {
+                if (valid) {
+                    if (nt_store) { od_st8_nt(crow, v[0]); od_st8_nt(crow + 32, v[1]); }
+                    else { od_st8(crow, v[0]); od_st8(crow + 32, v[1]); }
+                }
+                if (!roped) continue;
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) ss += v[0][e] * v[0][e] + v[1][e] * v[1][e];
+            ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+            const float invs = rsqrtf(ss / 64.f + rp.eps) * qs;
+            float t0[8], t1[8];                               // (cos, sin) of features 8g .. 8g+7 at this frame's position
+            const float* tb = rp.table + ((size_t)((valid ? gm : 0) % rp.L) * 32 + 8 * g) * 2;
+            od_ld8(tb, t0); od_ld8(tb + 8, t1);
+            float o0[8], o1[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float y0 = v[0][e] * invs * wv[0][e], y1 = v[1][e] * invs * wv[1][e];
+                const float cs = e < 4 ? t0[2 * e] : t1[2 * e - 8], sn = e < 4 ? t0[2 * e + 1] : t1[2 * e - 7];
+                o0[e] = y0 * cs - y1 * sn;
+                o1[e] = y1 * cs + y0 * sn;
+            }
+            if (valid) {
+                T* dst = qk ? qk + (size_t)gm * rp.ldqk + hc0 + 8 * g : crow;
+                od_st8(dst, o0); od_st8(dst + 32, o1);
+            }
+        }
+        return;
     }
     // lane (x, g): rows m0 + wm*128 + 16j + x, columns n0 + wn*64 + 32p + 8g .. +7
 #pragma unroll
@@ -725,20 +786,27 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
     const int tiles_m = quarter ? (M + 31) / 32 : half ? (M + 63) / 64 : (M + 127) / 128;
     const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
     const bool dma = (K % (128 / (int)sizeof(T))) == 0;
-    if (epi != OD_EPI_QKROPE && dma && M >= OD_GEMM_BIG_MIN_M && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
+    // q/k norm + RoPE in the large-M kernel's epilogue: bf16, head_dim 64 (a wave's 64 columns are one head), whole 256-column tiles
+    const bool big_rope = epi == OD_EPI_QKROPE && std::is_same<T, bf16_t>::value && rp.hd == 64 && rp.n_rope % 64 == 0 && N % 64 == 0 &&
+                          (!rp.qk_out || rp.ldqk % 8 == 0);
+    if ((epi != OD_EPI_QKROPE || big_rope) && dma && M >= OD_GEMM_BIG_MIN_M && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
         const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256;
         const int grid2 = ((tm2 + 7) / 8) * 8 * tn2;
         // Wide outputs are written with non-temporal stores: the 128 KiB tile bursts of 256 CUs (32 MiB, the size of all L2s) otherwise
         // evict the W / A lines the next tiles re-read, and this loop is bound by fetch latency x outstanding misses
         // (profiles/r02l_gemm_fetch_bound.txt): +7..12 % at N = 1024..2816, +2.5 % at 3072; at N = 512 (2 column tiles) it costs 3 %.
         const int nt_store = !accumulate && N >= OD_GEMM_NT_STORE_MIN_N;
-        if (epi == OD_EPI_SILU)
-            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_SILU>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, nt_store);
+        if (epi == OD_EPI_QKROPE) {
+            if constexpr (std::is_same<T, bf16_t>::value)
+                OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_QKROPE>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, 0, (rp.qk_out ? nt_store : 0), rp);
+        } else if (epi == OD_EPI_SILU)
+            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_SILU>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, nt_store, rp);
         else
-            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_NONE>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, nt_store);
+            OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_NONE>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, nt_store, rp);
         OD_CHECK_LAUNCH();
         return 0;
     }
+    if (epi == OD_EPI_QKROPE && rp.qk_out) return OD_ERR_UNSUPPORTED;      // the split form exists in the large-M kernel only (callers check)
 #define NT_GO(EPI_, DMA_, WMT_) OD_LAUNCH((gemm_nt_kernel<T, EPI_, DMA_, WMT_>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, rp)
 #define NT_GO2(EPI_, DMA_) do { if (quarter) NT_GO(EPI_, DMA_, 1); else if (half) NT_GO(EPI_, DMA_, 2); else NT_GO(EPI_, DMA_, 4); } while (0)
     if (epi == OD_EPI_QKROPE) {
@@ -826,7 +894,7 @@ extern "C" int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* 
     if (lda % ch || ldw % ch || K % ch || N % 8 || ldc % 8) return OD_ERR_ALIGN;
     const int n_rope = 2 * H * hd;
     if ((hd != 32 && hd != 64) || n_rope % 128 || n_rope > N) return OD_ERR_UNSUPPORTED;
-    const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps, q_scale};
+    const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps, q_scale, nullptr, 0};
     if (dtype == OD_BF16)
         return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
     if (dtype == OD_F32)
@@ -834,6 +902,24 @@ extern "C" int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* 
     if (dtype == OD_F32X3)
         return launch_nt<f32x3_t>((const f32x3_t*)A, lda, (const f32x3_t*)W, ldw, bias, (f32x3_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
     return OD_ERR_ARG;
+}
+
+extern "C" int od_gemm_nt_qkrope_split(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                                       void* qk_out, int ldqk, int M, int N, int K, const float* wq, const float* wk, const float* table,
+                                       int L, int H, int hd, float eps, float q_scale, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !bias || !wq || !wk || !table || L <= 0 || !qk_out || M % L) return OD_ERR_ARG;
+    const int ch = dtype == OD_BF16 ? 8 : 4;
+    if (lda % ch || ldw % ch || K % ch || N % 8 || ldc % 8 || ldqk % 8) return OD_ERR_ALIGN;
+    const int n_rope = 2 * H * hd;
+    if (n_rope > N) return OD_ERR_UNSUPPORTED;
+    // one launch where the large-M kernel's epilogue applies (bf16, head_dim 64, M >= OD_GEMM_BIG_MIN_M, K a multiple of 64); otherwise the two
+    // kernels it replaces
+    if (dtype == OD_BF16 && hd == 64 && M >= OD_GEMM_BIG_MIN_M && K % 64 == 0 && N % 64 == 0 && N >= 256) {
+        const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps, q_scale, qk_out, ldqk};
+        return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
+    }
+    if (int rc = od_gemm_nt(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, OD_EPI_NONE, 0, stream)) return rc;
+    return od_qk_norm_rope(dtype == OD_F32X3 ? OD_F32 : dtype, C, ldc, wq, wk, table, qk_out, ldqk, M / L, L, H, hd, eps, q_scale, stream);
 }
 
 extern "C" int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M,

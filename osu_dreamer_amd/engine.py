@@ -15,6 +15,7 @@ so every kernel sees aligned, zero-padded columns.
 """
 from __future__ import annotations
 
+
 import math
 from typing import Dict, List, Optional
 
@@ -204,10 +205,10 @@ class DenoiserEngine:
             #     kernel that closed the previous layer
             qkv = self.lbuf("qkv", i, (M, 3 * dh))
             if self.train or self.hd not in (32, 64) or (2 * dh) % 128:
-                ops.gemm_nt(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv, x3=self.x3)
                 qk = self.lbuf("qk", i, (M, 2 * dh))         # backward needs the pre-norm q, k as well
-                ops.qk_norm_rope(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, qk,
-                                 B, L, self.H, self.hd, FP32_EPS, q_scale=self.q_scale)
+                ops.gemm_nt_qkrope_split(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv, qk,
+                                         self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, L, self.H,
+                                         self.hd, FP32_EPS, x3=self.x3, q_scale=self.q_scale)
             else:                                             # no-grad: norm + RoPE in the GEMM's epilogue, in place
                 ops.gemm_nt_qkrope(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv,
                                    self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, L,

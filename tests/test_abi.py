@@ -14,7 +14,7 @@ def test_header_parses_every_entry_point():
     decls = _lib.parse_header()
     assert len(decls) >= 40
     for must in ("od_gemm_nt", "od_gemm_tn", "od_flash_attn_fwd", "od_flash_attn_bwd", "od_rmsnorm_film",
-                 "od_qk_norm_rope", "od_dwconv", "od_swiglu_rmsnorm", "od_uhead_fwd", "od_loss_grad",
+                 "od_qk_norm_rope", "od_gemm_nt_qkrope_split", "od_dwconv", "od_swiglu_rmsnorm", "od_uhead_fwd", "od_loss_grad",
                  "od_sampler_step", "od_adamw_ema", "od_graph_begin", "od_version", "od_error_string"):
         assert must in decls
 

@@ -152,6 +152,61 @@ def test_flash_attention_fwd_f32x3(dev, B, H, L, hd):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,hd,L,B,K", [(4, 64, 150, 2, 64), (2, 64, 70, 2, 64), (4, 32, 33, 3, 96), (6, 64, 130, 3, 128)])
+def test_gemm_nt_qkrope_split_equals_gemm_then_rope(dev, dtype, H, hd, L, B, K):
+    """The training-time form (pre-norm projection kept in C, normed + rotated q/k to a second buffer): identical C, q/k equal to
+    od_gemm_nt + od_qk_norm_rope up to the order of the 64-term sum of squares.  (4, 64, 150, 2) and (6, 64, 130, 3) run the
+    large-M kernel's fused epilogue on the emulator build (its large-M threshold is 256 rows); the rest take the two-kernel path."""
+    g = torch.Generator().manual_seed(33)
+    M, dh = B * L, H * hd
+    A, W, b = mk((M, K), g, dev, dtype), mk((3 * dh, K), g, dev, dtype, 0.3), mk((3 * dh,), g, dev)
+    wq, wk = 1 + 0.2 * mk((hd,), g, dev), 1 + 0.2 * mk((hd,), g, dev)
+    tab = torch.zeros(L, hd // 2, 2, device=dev)
+    ops.rope_table(tab, L, hd)
+    eps = 1.2e-7
+    qkv = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
+    ops.gemm_nt(A, W, b, qkv)
+    qk = torch.zeros(M, 2 * dh, dtype=dtype, device=dev)
+    ops.qk_norm_rope(qkv, wq, wk, tab, qk, B, L, H, hd, eps, q_scale=0.18)
+    raw = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
+    qk2 = torch.zeros(M, 2 * dh, dtype=dtype, device=dev)
+    ops.gemm_nt_qkrope_split(A, W, b, raw, qk2, wq, wk, tab, L, H, hd, eps, q_scale=0.18)
+    assert torch.equal(raw, qkv)
+    assert rel_l2(qk2.float(), qk.float()) < (2e-6 if dtype == torch.float32 else 3e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,K", [(5, 8192, 512), (3, 11001, 128)])
+def test_gemm_nt_qkrope_large_m(B, L, K):
+    """The fused epilogue of the 256x256 kernel at training-size M (ragged last row tile), both forms: split (training) and in place
+    (no-grad), against od_gemm_nt + od_qk_norm_rope."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    H, hd = 16, 64
+    g = torch.Generator().manual_seed(35)
+    M, dh = B * L, H * hd
+    A, W, b = mk((M, K), g, dev, bf), mk((3 * dh, K), g, dev, bf, 0.3), mk((3 * dh,), g, dev)
+    wq, wk = 1 + 0.2 * mk((hd,), g, dev), 1 + 0.2 * mk((hd,), g, dev)
+    tab = torch.zeros(L, hd // 2, 2, device=dev)
+    ops.rope_table(tab, L, hd)
+    eps = 1.2e-7
+    qkv = torch.zeros(M, 3 * dh, dtype=bf, device=dev)
+    ops.gemm_nt(A, W, b, qkv)
+    qk = torch.zeros(M, 2 * dh, dtype=bf, device=dev)
+    ops.qk_norm_rope(qkv, wq, wk, tab, qk, B, L, H, hd, eps, q_scale=0.18)
+    raw, qk2 = torch.zeros_like(qkv), torch.zeros_like(qk)
+    ops.gemm_nt_qkrope_split(A, W, b, raw, qk2, wq, wk, tab, L, H, hd, eps, q_scale=0.18)
+    assert torch.equal(raw, qkv)
+    assert float((qk2.float() - qk.float()).norm() / qk.float().norm()) < 3e-3
+    assert float((qk2.float() - qk.float()).abs().max()) < 0.1
+    fused = torch.zeros_like(qkv)
+    ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps, q_scale=0.18)
+    assert torch.equal(fused[:, 2 * dh:], qkv[:, 2 * dh:])
+    assert torch.equal(fused[:, :2 * dh], qk2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 136, 72), (64, 16, 24), (1000, 130, 170), (600, 264, 300)])
 def test_gemm_tn_colsum(dev, dtype, M, N, K):
     g = torch.Generator().manual_seed(2)
