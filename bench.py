@@ -97,17 +97,43 @@ def bwd_passes_executed():
     return int(_lib.lib().cdll.od_flash_attn_bwd_passes())
 
 
+def _lib_sha():
+    from osu_dreamer_amd import _lib
+    return _lib.source_sha()
+
+
 def load_pmc(B, L):
-    """PMC results of THIS round's kernels (profiles/r02_traffic.json, written by tools/pmc_step.sh + tools/pmc_summary.py from
-    separate FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES rocprofv3 passes over one bench step: counters cannot be read
-    in-process).  Returns (HBM bytes per od_flash_attn_bwd launch, per-kernel-class table) or (None, None)."""
-    try:
-        tr_ = json.load(open(os.path.join(REPO, "profiles", "r02_traffic.json")))
-        if (B, L) == (tr_.get("B"), tr_.get("L")):
+    """PMC results of the kernels THIS library was built from: the newest profiles/r*_traffic.json (written by tools/pmc_step.sh +
+    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES rocprofv3 passes over one bench step: counters
+    cannot be read in-process) whose `kernel_src_sha` equals od_build_source_sha() of the loaded library.  A record taken on another
+    build is NOT quoted.  Returns (HBM bytes per od_flash_attn_bwd launch, per-kernel-class table, source tag) or (None, None, tag)."""
+    import glob
+    sha = _lib_sha()
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            tr_ = json.load(open(path))
+        except Exception:
+            continue
+        if tr_.get("kernel_src_sha") == sha and (B, L) == (tr_.get("B"), tr_.get("L")):
             e = tr_["od_flash_attn_bwd"]
-            return int(e["read_bytes"] + e["write_bytes"]), tr_.get("classes")
-    except Exception:
-        pass
+            return (int(e["read_bytes"] + e["write_bytes"]), tr_.get("classes"),
+                    {"source": os.path.relpath(path, REPO), "kernel_src_sha": sha})
+    return None, None, {"source": None, "kernel_src_sha": sha,
+                        "note": "no profiles/r*_traffic.json was taken on this build (or at this batch x frames): counters not quoted"}
+
+
+def load_sampler_parity():
+    """tests/test_sampler50.py's record of the 50-step sampler against the REFERENCE's own run (tests/golden/sample50_full_d8_b4_l1115.npz),
+    committed as profiles/r*_sampler_parity.json; quoted only when it was measured on this build."""
+    import glob
+    sha = _lib_sha()
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_sampler_parity.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("kernel_src_sha") == sha:
+            return rec, os.path.relpath(path, REPO)
     return None, None
 
 
@@ -133,21 +159,21 @@ def roofline_of_dominant_kernel(tr, B, L):
     unit = 2.0 * B * H * L * L * hd                 # one L x L x hd MFMA pass over all heads
     t_bwd, t_fwd = time_kernel(bwd), time_kernel(fwd)
     executed = bwd_passes_executed()
-    traffic, classes = load_pmc(B, L)
+    traffic, classes, traffic_src = load_pmc(B, L)
     ach_bwd = BWD_PASSES_ALGORITHMIC * unit / t_bwd / 1e12
     ach_fwd = 2 * unit / t_fwd / 1e12
     return {
         "bound": "mfma", "kernel": "od_flash_attn_bwd (attention backward of one layer)",
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+        "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "ms_per_launch": round(t_bwd * 1e3, 3),
         "flops_counted": f"algorithmic: {BWD_PASSES_ALGORITHMIC} passes x 2*B*H*L^2*hd",
         "mfma_passes_executed": executed,
         "achieved_executed": round(executed * unit / t_bwd / 1e12, 1),
         "also": {"od_flash_attn_fwd": {"achieved": round(ach_fwd, 1), "frac": round(ach_fwd / PEAK_BF16_TFLOPS, 4),
                                        "ms_per_launch": round(t_fwd * 1e3, 3)},
-                 # per kernel class over one step, from the committed PMC passes (profiles/r02j_pmc_step.txt): HBM fraction of
-                 # 8 TB/s for the memory-bound classes, MFMA-pipe busy fraction for the matrix classes
+                 # per kernel class over one step, from the same PMC record as `traffic` (null when that record is not of this build):
+                 # HBM fraction of 8 TB/s for the memory-bound classes, MFMA-pipe busy fraction for the matrix classes
                  "pmc_classes": classes},
     }
 
@@ -216,6 +242,14 @@ def sampler_bench(device):
         dt_s = time.time() - t0
         out[name] = {"latents_per_s": round(B * L / dt_s, 1), "ms_per_sample_call": round(dt_s * 1e3, 2),
                      "tflops": round(51 * flops_forward(B * L, L) / dt_s / 1e12, 1)}
+    # which of these modes meets north_star's "within 1e-4 relative L2 of reference" — measured by tests/test_sampler50.py against the
+    # reference's own 50-step run at this very size; quoted only when that record is of the build being benchmarked
+    rec, src = load_sampler_parity()
+    for name in out:
+        mode = (rec or {}).get("modes", {}).get(name)
+        out[name]["meets_1e-4"] = None if mode is None else bool(mode["meets_1e-4"])
+        out[name]["rel_l2_vs_reference"] = None if mode is None else float(mode["rel_l2_vs_reference_fp32"])
+    out["parity_source"] = src if rec else "no profiles/r*_sampler_parity.json of this build (run pytest -m gpu tests/test_sampler50.py)"
     return {"workload": "50-step sampler, B=4, L=1115, audio batch 1 (broadcast), hipGraph", **out}
 
 
@@ -347,17 +381,26 @@ def main():
 
     for i in range(args.warmup):
         loss = step(i)
+    if reducer is not None:
+        reducer.exposed_ms()                   # drop the warm-up's events
+        reducer.time_exposed = True            # HIP events either side of the compute stream's wait for the exchange (no host sync)
     barrier()
     t0 = time.time()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     dt = time.time() - t0
+    per_rank = None
     if ddp:
         import torch.distributed as dist
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+        # every rank's own wall time and exposed-communication time, so that a slow rank or an un-hidden exchange shows in the line
+        exposed = reducer.exposed_ms()
+        mine = torch.tensor([dt / args.steps * 1e3, sum(exposed) / max(len(exposed), 1), max(exposed, default=0.0)],
+                            device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu()
+        dt = float(per_rank[:, 0].max()) * args.steps / 1e3
     final_loss = float(loss.detach())
 
     if rank == 0:
@@ -367,7 +410,7 @@ def main():
         # executed MFMA work: forward + 2x GEMM backward + attention backward as its executed passes (vs 2 forward)
         attn_fwd = frames * 32_768 * L
         executed = f_fwd + 2 * (f_fwd - attn_fwd) + bwd_passes_executed() / 2 * attn_fwd
-        named = {(32, 8192): "BASELINE.json configs[1]", (8, 32768): "BASELINE.json configs[4] shape, bf16 compute",
+        named = {(32, 8192): "BASELINE.json configs[1]", (8, 32768): "BASELINE.json configs[4] shape; attention in bf16 MFMA where configs[4] says fp16 (same MFMA rate, no loss scaling)",
                  (2, 4096): "BASELINE.json configs[0] shape, on the GPU"}.get((B, L), "custom --batch/--frames")
         if world > 1 and (B, L) == (32, 8192):
             named = f"BASELINE.json configs[2] pattern at {world} ranks (configs[1] per rank)"
@@ -392,7 +435,16 @@ def main():
         if ddp:
             line["collective"] = {"backend": "RCCL via od_allreduce_grads", "version": reducer.comm.version,
                                   "exchange": "od_allreduce_grads per arena segment (187.5 MB fp32 per step), overlapped with backward",
-                                  "world_size": world}
+                                  "world_size": world, "rccl_ranks_seen": reducer.comm.ranks_seen,
+                                  # time the compute stream waited for the side-stream exchange before clip / AdamW (HIP events): mean
+                                  # over steps, averaged and maximised over ranks; 0 = fully hidden under the backward
+                                  "allreduce_exposed_ms": round(float(per_rank[:, 1].mean()), 3),
+                                  "allreduce_exposed_ms_max_rank": round(float(per_rank[:, 1].max()), 3),
+                                  "allreduce_exposed_ms_worst_step": round(float(per_rank[:, 2].max()), 3),
+                                  "ms_per_step_min_rank": round(float(per_rank[:, 0].min()), 2),
+                                  "ms_per_step_max_rank": round(float(per_rank[:, 0].max()), 2),
+                                  "ms_per_step_per_rank": [round(float(x), 2) for x in per_rank[:, 0]],
+                                  "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         if not args.no_extras and world == 1:
             line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
             line["forward_64x8192"] = forward_target_shape(tr, device)

@@ -34,6 +34,9 @@ enum { OD_ACT_NONE = 0, OD_ACT_SILU = 1 };
 enum { OD_ERR_ARG = -1, OD_ERR_ALIGN = -2, OD_ERR_UNSUPPORTED = -3, OD_ERR_COMM = -4 };
 
 int od_version(void);
+/* 16 hex digits: hash of the kernel sources (csrc/*.hip, *.h, this header, extra compiler flags) the library was built from.
+ * Measurement records under profiles/ quote it; bench.py refuses a record taken on another build. */
+const char* od_build_source_sha(void);
 const char* od_error_string(int code);
 
 /* ---- GEMMs: every nn.Conv1d(k=1) / nn.Linear on the path ------------------------ */
@@ -266,6 +269,10 @@ int od_comm_unique_id(void* out, int nbytes);
  * current device). */
 int od_comm_init(void** comm_out, int nranks, int rank, const void* unique_id, int nbytes);
 int od_comm_destroy(void* comm);
+/* failure path (a peer died): ncclCommAbort — frees the communicator without waiting for collectives that can no longer complete */
+int od_comm_abort(void* comm);
+/* number of ranks RCCL itself counts in the communicator (ncclCommCount), or a negative error: the bench line's `rccl_ranks_seen` */
+int od_comm_count(void* comm);
 /* grads[0:count] (fp32, device) <- sum over ranks (average != 0: mean) in place, enqueued on `stream`: the one exchange
  * of a data-parallel training step (the gradient of train.py:120-123's loss over the global batch). */
 int od_allreduce_grads(void* comm, float* grads, long count, int average, void* stream);

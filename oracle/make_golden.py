@@ -550,6 +550,48 @@ def gen_round2(out_dir):
     gen_validation(out_dir, "val_full_d2", O.Dims(depth=2), val_batches=8, l=8 * 24 + 5, seed=1200)
 
 
+def gen_sampler50(out_dir, name, d: O.Dims, B, L, seed, num_steps=50, with_bf16=True):
+    """BASELINE configs[3] where north_star claims it: the reference's DiffusionModel.sample (models/diffusion/model.py:117-138)
+    for `num_steps` steps (num_steps + 1 network evaluations) with batch-1 audio broadcast against B styles
+    ('#B A l', model.py:120).  Weights and inputs are regenerated from the seed on both sides; the fixture holds the
+    whole (B, E, L) output (~100 KB), the reference's u0 / eta (recomputed the way model.py:131-132 does), the first
+    evaluation's (u, v), and -- as the anchor of the bf16 tolerance -- the same call under torch.autocast(bfloat16)."""
+    import osu_dreamer.models.diffusion.model as model_mod
+    P = O.init_params(d, seed=seed)
+    data = O.synthetic_batch(d, B, L, seed=seed + 1, audio_batch=1)
+    m = _ref_model(d, P).eval()
+    fx = {"dims": np.array(list(d.to_dict().values())), "B": B, "L": L, "seed": seed, "num_steps": num_steps}
+    saved = model_mod.th.randn
+    model_mod.th.randn = lambda *a, **k: data["x_init"].clone()
+    try:
+        import time
+        t0 = time.time()
+        xs = m.sample(data["h"], data["s"], num_steps)
+        fx["ref_cpu_seconds"] = time.time() - t0
+        with torch.no_grad():
+            u0, v0 = m(data["h"], data["s"], data["x_init"])
+        c0 = float(m.c0)
+        eta = 1 - (c0 ** .5 / max(float(u0.mean()), c0 ** .5 + 1e-6)) ** (1 / num_steps)
+        fx.update(sample_x=xs, u0=u0, v0=v0, eta=eta)
+        if with_bf16:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                xb = m.sample(data["h"], data["s"], num_steps)
+            fx["sample_x_bf16"] = xb.float()
+    finally:
+        model_mod.th.randn = saved
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
+    msg = f"{name}: |x| {float(xs.norm()):.4f} eta {eta:.6f} ref cpu {fx['ref_cpu_seconds']:.1f}s"
+    if with_bf16:
+        msg += f" bf16-vs-f32 rel-L2 {float((xb.float() - xs).norm() / xs.norm()):.3e}"
+    print(msg, flush=True)
+
+
+def gen_round3(out_dir):
+    # 50 steps of the full 46.9 M-parameter model: at a short length, and at configs[3] (B=4, L=1115: a 3-minute song)
+    gen_sampler50(out_dir, "sample50_full_d8_b2_l64", O.FULL, B=2, L=64, seed=1300)
+    gen_sampler50(out_dir, "sample50_full_d8_b4_l1115", O.FULL, B=4, L=1115, seed=1400)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -558,6 +600,9 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     if os.environ.get("GOLDEN_ONLY") == "round2":
         gen_round2(out_dir)
+        return
+    if os.environ.get("GOLDEN_ONLY") == "round3":
+        gen_round3(out_dir)
         return
     gen_lr(out_dir)
     gen_ops(out_dir)
@@ -592,6 +637,7 @@ def main():
     gen_model(out_dir, "full_d8_b2_l64", O.FULL, B=2, L=64, seed=400, store_weights=False,
               num_steps=4)
     gen_round2(out_dir)
+    gen_round3(out_dir)
 
 
 if __name__ == "__main__":

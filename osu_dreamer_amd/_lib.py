@@ -98,3 +98,8 @@ def use_library(path: str) -> _Lib:
 
 def loaded_path() -> Optional[str]:
     return _lib.path if _lib is not None else None
+
+
+def source_sha() -> str:
+    """Hash of the kernel sources the loaded library was built from (od_build_source_sha)."""
+    return lib().cdll.od_build_source_sha().decode()

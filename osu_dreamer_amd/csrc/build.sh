@@ -27,5 +27,7 @@ for s in $SRCS; do
   OBJS="$OBJS $o"
 done
 for p in $PIDS; do wait $p || { echo "hipcc failed" >&2; exit 1; }; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $OUT
-echo "built $OUT"
+SHA=$(bash ./source_sha.sh)
+g++ -O1 -fPIC -DOD_SRC_SHA="\"$SHA\"" -c version.cpp -o build/version.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS build/version.o -ldl -o $OUT
+echo "built $OUT ($SHA)"

@@ -16,6 +16,8 @@ extern "C" int od_comm_version(void) { return 0; }
 extern "C" int od_comm_unique_id(void*, int) { return OD_ERR_UNSUPPORTED; }
 extern "C" int od_comm_init(void**, int, int, const void*, int) { return OD_ERR_UNSUPPORTED; }
 extern "C" int od_comm_destroy(void*) { return OD_ERR_UNSUPPORTED; }
+extern "C" int od_comm_abort(void*) { return OD_ERR_UNSUPPORTED; }
+extern "C" int od_comm_count(void*) { return OD_ERR_UNSUPPORTED; }
 extern "C" int od_allreduce_grads(void*, float*, long, int, void*) { return OD_ERR_UNSUPPORTED; }
 extern "C" int od_broadcast_f32(void*, float*, long, int, void*) { return OD_ERR_UNSUPPORTED; }
 #else
@@ -37,6 +39,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
 };
@@ -54,6 +58,7 @@ int load(const char* path) {
     if (!g_rccl.handle) return OD_ERR_COMM;
     const bool ok = bind(g_rccl.GetVersion, "ncclGetVersion") && bind(g_rccl.GetUniqueId, "ncclGetUniqueId") &&
                     bind(g_rccl.CommInitRank, "ncclCommInitRank") && bind(g_rccl.CommDestroy, "ncclCommDestroy") &&
+                    bind(g_rccl.CommAbort, "ncclCommAbort") && bind(g_rccl.CommCount, "ncclCommCount") &&
                     bind(g_rccl.AllReduce, "ncclAllReduce") && bind(g_rccl.Broadcast, "ncclBroadcast");
     if (!ok) { dlclose(g_rccl.handle); g_rccl = Rccl(); return OD_ERR_COMM; }
     return 0;
@@ -92,6 +97,19 @@ extern "C" int od_comm_init(void** comm_out, int nranks, int rank, const void* u
 extern "C" int od_comm_destroy(void* comm) {
     if (!comm || !g_rccl.handle) return OD_ERR_ARG;
     return g_rccl.CommDestroy((ncclComm_t)comm) == 0 ? 0 : OD_ERR_COMM;
+}
+
+// failure path: frees the communicator without waiting for outstanding collectives (a peer that died never completes them)
+extern "C" int od_comm_abort(void* comm) {
+    if (!comm || !g_rccl.handle) return OD_ERR_ARG;
+    return g_rccl.CommAbort((ncclComm_t)comm) == 0 ? 0 : OD_ERR_COMM;
+}
+
+// ranks RCCL itself counts in the communicator (>= 1), or a negative error
+extern "C" int od_comm_count(void* comm) {
+    if (!comm || !g_rccl.handle) return OD_ERR_ARG;
+    int n = 0;
+    return g_rccl.CommCount((ncclComm_t)comm, &n) == 0 ? n : OD_ERR_COMM;
 }
 
 extern "C" int od_allreduce_grads(void* comm, float* grads, long count, int average, void* stream) {

@@ -15,11 +15,10 @@
 // kernels whose dynamic LDS may exceed the 64 KiB default (gfx950 has 160 KiB per CU)
 #define OD_LAUNCH_DYN(kern, grid, block, smem, stream, ...)                                                    \
     do {                                                                                                       \
-        static bool attr_set__ = false;                                                                        \
-        if (!attr_set__) {                                                                                     \
-            (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set__ = true;                                                                                 \
-        }                                                                                                      \
+        /* once per process (one process drives one GPU): a refused attribute is an error code, not a silent 64 KiB limit */ \
+        static const hipError_t attr_rc__ =                                                                    \
+            hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+        if (attr_rc__ != hipSuccess) return -(int)attr_rc__ - 1000;                                            \
         hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);                              \
     } while (0)
 #define OD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -254,9 +253,10 @@ __device__ __forceinline__ void od_glds16(const void* g, void* lds) {
 struct od_srd_t { const unsigned char* base; unsigned bytes; };
 __device__ __forceinline__ od_srd_t od_make_srd(const void* base, unsigned bytes) { return od_srd_t{(const unsigned char*)base, bytes}; }
 __device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsigned soff, void* lds) {
+    // the hardware range-checks per DWORD: the in-range dwords of a chunk that straddles the end of the buffer are loaded
     alignas(16) unsigned char tmp[16] = {0};
     const unsigned off = voff + soff;
-    if (off + 16 <= r.bytes) memcpy(tmp, r.base + off, 16);
+    if (off < r.bytes) { const unsigned n = (r.bytes - off) & ~3u; memcpy(tmp, r.base + off, n < 16 ? n : 16); }
     emu::global_load_lds16(tmp, (unsigned char*)lds + 16 * emu::lane_id());
 }
 __device__ __forceinline__ int od_uniform(int x) { return x; }

@@ -52,6 +52,9 @@ class RcclComm:
         with torch.cuda.device(device):
             L.od_comm_init(ctypes.byref(self._comm), self.world, self.rank, ident, UNIQUE_ID_BYTES)
         self.version = int(L.cdll.od_comm_version())
+        self.ranks_seen = int(L.cdll.od_comm_count(self._comm))     # ncclCommCount: what RCCL itself believes the world is
+        if self.ranks_seen != self.world:
+            raise RuntimeError(f"RCCL communicator holds {self.ranks_seen} ranks, torch.distributed says {self.world}")
 
     def allreduce_mean_(self, t: torch.Tensor):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
@@ -61,10 +64,14 @@ class RcclComm:
         assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
         _lib.lib().od_broadcast_f32(self._comm, t.data_ptr(), t.numel(), root, torch.cuda.current_stream(t.device).cuda_stream)
 
-    def close(self):
+    def close(self, abort: bool = False):
+        """`abort`: the failure path (a peer died, collectives in flight can never complete) — ncclCommAbort, no device sync."""
         if self._comm:
-            torch.cuda.synchronize()
-            _lib.lib().od_comm_destroy(self._comm)
+            if abort:
+                _lib.lib().od_comm_abort(self._comm)
+            else:
+                torch.cuda.synchronize()
+                _lib.lib().od_comm_destroy(self._comm)
             self._comm = ctypes.c_void_p()
 
 
@@ -80,6 +87,10 @@ class GradBucketReducer:
         self._handles: List = []
         self._comm_stream: Optional[torch.cuda.Stream] = None
         self._done = set()
+        # exposed communication: HIP events on the compute stream either side of its wait for the side stream, i.e. how long the
+        # optimizer had to wait for the exchange after the backward's own kernels were done (0 when the overlap is perfect)
+        self.time_exposed = False
+        self._exposed_events: List = []
         dev = model.arena.data.device
         self.comm: Optional[RcclComm] = RcclComm(dev, process_group) if dev.type == "cuda" else None
         model._reducer = self
@@ -145,13 +156,29 @@ class GradBucketReducer:
                 h.wait()
                 g.div_(self.world)
         if self._comm_stream is not None:
-            torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
+            cur = torch.cuda.current_stream(self._comm_stream.device)
+            if self.time_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self._comm_stream)
+                e1.record(cur)
+                self._exposed_events.append((e0, e1))
+            else:
+                cur.wait_stream(self._comm_stream)
         self._handles.clear()
         self._done.clear()
 
-    def close(self):
+    def exposed_ms(self, reset: bool = True) -> List[float]:
+        """Per step since the last reset: milliseconds the compute stream spent waiting for the gradient exchange (synchronises)."""
+        torch.cuda.synchronize()
+        out = [e0.elapsed_time(e1) for e0, e1 in self._exposed_events]
+        if reset:
+            self._exposed_events.clear()
+        return out
+
+    def close(self, abort: bool = False):
         if self.comm is not None:
-            self.comm.close()
+            self.comm.close(abort=abort)
 
 
 class StepAgreement:

@@ -185,7 +185,6 @@ class DenoiserEngine:
         f32 = torch.float32
         tab = self.ws.t["rope"]
         bcast = self.Ba == 1 and B > 1
-        self.draw_dropout_masks()                             # a fresh channel mask per evaluation, like nn.Dropout1d
         x = self.lbuf("x_in", 0, (M, D))
         ops.proj_in(xt, self.P("proj_in.weight"), self.P("proj_in.bias"), x)
 
@@ -236,7 +235,7 @@ class DenoiserEngine:
             hh = self.lbuf("hh", i, (M, Hp))
             ops.swiglu_rmsnorm(vg, hh, self.lbuf("inv4", i, (M,), f32), self.Hf, Hp)
             if self._drop_active():                           # nn.Dropout1d, training mode only (swiglu.py:23,30)
-                ops.scale_channels(hh, self._drop_mask(i), B, L)
+                ops.scale_channels(hh, self.draw_dropout_mask(i), B, L)
             fo = self.lbuf("fo", i, (M, D))
             ops.gemm_nt(hh, self.W(p + "ffn.proj_o"), self.P(p + "ffn.proj_o.bias"), fo, x3=self.x3)
             # next layer input (at inference x_in.0 / x_in.1 ping-pong), together with the next layer's h1
@@ -272,13 +271,15 @@ class DenoiserEngine:
     def _drop_mask(self, i: int) -> torch.Tensor:
         return self.ws.t[f"drop.{i}"]
 
-    def draw_dropout_masks(self):
-        if not self._drop_active():
-            return
+    def draw_dropout_mask(self, i: int) -> torch.Tensor:
+        """Layer i's mask, drawn where the reference draws it (inside the layer's SwiGLU, swiglu.py:30) and the way nn.Dropout1d does:
+        one Bernoulli(keep) per (batch, channel) over the Hf real channels, scaled by 1/keep; zero-extended to the padded width.
+        (The draw consumes the device generator in the reference's order; bit-equal masks across devices are not a goal.)"""
         keep = 1.0 - self.dropout
-        for i in range(self.depth):
-            m = self.buf(f"drop.{i}", (self.B, self.Hp), torch.float32)
-            m.copy_((torch.rand(self.B, self.Hp, device=m.device) < keep).to(torch.float32) / keep)
+        m = self.buf(f"drop.{i}", (self.B, self.Hp), torch.float32)
+        m.zero_()
+        m[:, :self.Hf] = torch.empty(self.B, self.Hf, device=m.device, dtype=torch.float32).bernoulli_(keep) / keep
+        return m
 
     def _uhead_w(self, grads=False):
         f = self.G if grads else self.P

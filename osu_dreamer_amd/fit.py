@@ -70,14 +70,15 @@ class Trainer:
         self.enable_checkpointing = enable_checkpointing
         self.global_step, self.epoch = 0, 0
         self.best_val = float("inf")
-        # `devices: N` = N ranks, one per GPU (model.yml:11).  The ranks are started by `fit_denoiser` / the CLI
-        # (launch.spawn_ranks_if_needed) before anything touches the GPU; inside a rank WORLD_SIZE must agree.
+        # `devices: N` = N ranks, one per GPU (model.yml:11).  The ranks are started by the CLI (`python -m osu_dreamer_amd
+        # fit-denoiser` -> launch.spawn_ranks_if_needed) or by the caller's own torchrun, before anything touches the GPU; inside a rank
+        # WORLD_SIZE and `devices` must agree in BOTH directions (devices: 1 under a 4-rank torchrun is a mistake, not a 4-GPU run).
         self.devices = launch.parse_devices(devices)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if self.devices > 1 and self.world != self.devices:
-            raise RuntimeError(f"trainer.devices={self.devices} but WORLD_SIZE={self.world}: start the run through "
-                               "`python -m osu_dreamer_amd fit-denoiser` / fit_denoiser() (they spawn the ranks), or under "
-                               f"`torchrun --nproc-per-node {self.devices}`")
+        if self.world != self.devices:
+            raise RuntimeError(f"trainer.devices={self.devices} but WORLD_SIZE={self.world}: start the run with "
+                               "`python -m osu_dreamer_amd fit-denoiser` (it spawns one rank per device) or under "
+                               f"`torchrun --nproc-per-node {self.devices}`, and keep trainer.devices equal to the rank count")
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.history = []
@@ -128,12 +129,41 @@ class Trainer:
             device = torch.device("cpu")     # test-suite only: kernels bound to the SIMT emulator build
         else:
             raise RuntimeError("fit-denoiser needs an MI355X: osu_dreamer_amd has no CPU path")
-        reducer = None
+        reducer, own_group = None, False
         if self.world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
                 dist.init_process_group("nccl" if device.type == "cuda" else "gloo",
                                         **({"device_id": device} if device.type == "cuda" else {}))
+                own_group = True
+        try:
+            out = self._fit(module, datamodule, ckpt_path, device)
+        except BaseException:
+            # failure (possibly a dead peer): nothing that waits for the device or for other ranks — abort the RCCL communicator and let
+            # the exception end the process; the launcher (torchrun agent) then stops the remaining ranks and returns non-zero
+            reducer = getattr(module.diffusion, "_reducer", None)
+            if reducer is not None:
+                try:
+                    reducer.close(abort=True)
+                except Exception:
+                    pass
+                module.diffusion._reducer = None
+            raise
+        # orderly teardown: drain the device, destroy the communicator the C ABI created, then the process group — but only a group this
+        # call initialised (left to interpreter exit the order is arbitrary and RCCL can hang or abort there)
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        reducer = getattr(module.diffusion, "_reducer", None)
+        if reducer is not None:
+            reducer.close()
+            module.diffusion._reducer = None
+        if own_group:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return out
+
+    def _fit(self, module, datamodule, ckpt_path, device):
+        reducer = None
         module.gradient_clip_val = self.gradient_clip_val
         module.to(device)
         cfg = module.configure_optimizers()
@@ -230,8 +260,10 @@ def fit_denoiser(config: str = DEFAULT_CONFIG, ckpt_path: Optional[str] = None, 
         seed_everything(cfg["seed_everything"])
     devices = launch.parse_devices(cfg.get("trainer", {}).get("devices", 1))
     if devices > 1 and launch.world_from_env() is None:
-        raise RuntimeError("fit_denoiser(devices > 1) must run inside a rank: use `python -m osu_dreamer_amd fit-denoiser` "
-                           "(it starts the ranks) or torchrun")
+        # this function runs INSIDE a rank; only the CLI (main(), below) starts ranks, because that has to happen in a process
+        # that never touches the GPU
+        raise RuntimeError(f"fit_denoiser() with trainer.devices={devices} must run inside a rank: use `python -m osu_dreamer_amd "
+                           f"fit-denoiser` (it starts the {devices} ranks) or `torchrun --nproc-per-node {devices}`")
     module, trainer = build_from_config(cfg)
     data = LatentDataModule(**cfg["data"], rank=trainer.rank, world_size=trainer.world)
     trainer.fit(module, data, ckpt_path=ckpt_path)
@@ -244,7 +276,11 @@ def main(argv=None):
     f = sub.add_parser("fit-denoiser", help="begin a training run for the diffusion model")
     f.add_argument("-c", "--config", default=DEFAULT_CONFIG)
     f.add_argument("--ckpt-path", default=None)
+    from . import predict as predict_cmd
+    predict_cmd.add_parser(sub)
     a = ap.parse_args(argv)
+    if a.cmd == "predict":
+        return predict_cmd.run(a)
     if a.cmd == "fit-denoiser":
         with open(a.config) as fh:
             devices = launch.parse_devices((yaml.safe_load(fh).get("trainer") or {}).get("devices", 1))

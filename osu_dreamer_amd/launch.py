@@ -64,6 +64,11 @@ def spawn_ranks_if_needed(n: int, script_args: Sequence[str], module: Optional[s
     if n <= 1 or world_from_env() is not None:
         return None
     e = dict(os.environ if env is None else env)
-    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    # dmabuf IPC: on this driver RCCL's cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument` under the legacy
+    # mode.  A value already in the environment wins (so the knob can be turned without editing code); what the ranks run with is logged.
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[osu_dreamer_amd.launch] starting {n} ranks; HSA_ENABLE_IPC_MODE_LEGACY={e['HSA_ENABLE_IPC_MODE_LEGACY']}"
+          f"{' (from the environment)' if 'HSA_ENABLE_IPC_MODE_LEGACY' in (os.environ if env is None else env) else ' (default)'}",
+          file=sys.stderr, flush=True)
     e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     return subprocess.call(torchrun_command(n, script_args, module), env=e)

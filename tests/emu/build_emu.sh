@@ -17,5 +17,7 @@ for s in gemm rowops misc heads optim attn style latent comm; do
   OBJS="$OBJS $o"
 done
 for p in $PIDS; do wait $p || { echo "emulator build failed" >&2; exit 1; }; done
-/opt/rocm/lib/llvm/bin/clang++ -shared -fPIC $OBJS -o $OUT
+SHA=$(bash $CS/source_sha.sh)
+g++ -O1 -fPIC -DOD_SRC_SHA="\"$SHA\"" -c $CS/version.cpp -o build/version.o
+/opt/rocm/lib/llvm/bin/clang++ -shared -fPIC $OBJS build/version.o -o $OUT
 echo "built $OUT"

@@ -183,3 +183,60 @@ def test_bench_gpus_flag_starts_ranks(monkeypatch):
         bench.main()
     assert e.value.code == 0
     assert calls and calls[0][0] == 4 and calls[0][1][0].endswith("bench.py") and calls[0][1][1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a rank that dies mid-epoch must take the job down with a non-zero exit, not leave its peers waiting in a collective
+_DEAD_RANK_SCRIPT = r'''
+import os, sys, time
+repo, data_dir, out_dir = sys.argv[1:4]
+sys.path.insert(0, repo); sys.path.insert(0, os.path.join(repo, "tests"))
+import torch
+torch.set_num_threads(2)
+from osu_dreamer_amd import _lib
+from osu_dreamer_amd.data import LatentDataModule
+from osu_dreamer_amd.fit import build_from_config
+from kernel_backend import EMU_SO
+from test_fit import _cfg
+_lib.use_library(EMU_SO)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+cfg = _cfg(True)
+cfg["data"].update(data_path=data_dir, seq_len=24, batch_size=1, num_workers=0, shuffle_buffer_size=1, max_val_count=1, max_val_frac=.3, max_per_map=-1)
+cfg["trainer"].update(max_epochs=50, max_steps=-1, log_every_n_steps=1, limit_val_batches=1, devices=world,
+                      default_root_dir=os.path.join(out_dir, f"run{rank}"), precision="32", enable_checkpointing=False)
+module, trainer = build_from_config(cfg)
+hook = module.on_train_batch_end
+def dying_hook(*a, **k):
+    hook(*a, **k)
+    open(os.path.join(out_dir, f"alive{rank}"), "a").write("x")
+    if rank == 1 and trainer.global_step >= 2:
+        os._exit(17)                      # no teardown, no goodbye: the process is simply gone
+module.on_train_batch_end = dying_hook
+dm = LatentDataModule(**cfg["data"], rank=rank, world_size=world)
+trainer.fit(module, dm)                   # initialises (and would destroy) the gloo group itself
+open(os.path.join(out_dir, f"finished{rank}"), "w").write("done")
+'''
+
+
+@pytest.mark.timeout(600)
+def test_dead_rank_ends_the_job_nonzero(tmp_path):
+    """Rank 1 vanishes (os._exit) after its 3rd step of a 50-epoch run.  The launcher's job must END — rank 0 must not sit in the
+    step agreement / all-reduce forever — and must report failure (non-zero).  The watchdog is the launcher's agent plus the
+    failure path of Trainer.fit (abort the communicator, re-raise): never a re-exec of a process that has touched the GPU."""
+    import time
+    from kernel_backend import build_emu
+    from osu_dreamer_amd import launch
+    from osu_dreamer_amd.data import write_synthetic_dataset
+    build_emu()
+    data_dir = tmp_path / "data"
+    write_synthetic_dataset(str(data_dir), n_maps=5, frames=96, a_dim=16, emb_dim=6, style_dim=8, seed=4)
+    script = tmp_path / "dying_fit.py"
+    script.write_text(_DEAD_RANK_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    rc = launch.spawn_ranks_if_needed(2, [str(script), REPO, str(data_dir), str(tmp_path)], env=env)
+    dt = time.time() - t0
+    assert rc not in (0, None), "a job that lost a rank must not report success"
+    assert dt < 300, f"the surviving rank took {dt:.0f} s to give up"
+    assert (tmp_path / "alive0").exists() and (tmp_path / "alive1").exists(), "both ranks were training before the failure"
+    assert not (tmp_path / "finished0").exists() and not (tmp_path / "finished1").exists()

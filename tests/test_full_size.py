@@ -98,10 +98,10 @@ def test_attention_backward_vs_autograd_full_length(dev, L):
         assert rel(dv.float(), vr.grad) < tol and rel(dk.float(), kr.grad) < 1.5 * tol and rel(dq.float(), qr.grad) < 1.5 * tol
 
 
+@pytest.mark.parametrize("M", [16 * 8192, 32 * 8192])      # 32 x 8192 = 262,144 rows: the bench's own M (its split counts, its XCD tile order)
 @pytest.mark.parametrize("N,K", [(3072, 512), (512, 1024), (2816, 512), (512, 1408), (512, 3072)])
-def test_gemm_bench_shapes_vs_torch(dev, N, K):
+def test_gemm_bench_shapes_vs_torch(dev, N, K, M):
     from osu_dreamer_amd import ops
-    M = 16 * 8192
     g = torch.Generator(device=dev).manual_seed(2)
     bf = torch.bfloat16
     A = torch.randn(M, K, device=dev, generator=g).to(bf)
@@ -189,6 +189,57 @@ def test_bf16_step_agrees_with_fp32_step(dev, B, L):
         worst = max(worst, e)
         assert e < 6e-2, (seg, e)
     print(f"[B={B} L={L}] bf16 vs fp32 step: loss {l16:.5f} / {l32:.5f}, |g| {n16:.4f} / {n32:.4f}, cos {cos:.6f}, worst segment rel-L2 {worst:.3e}")
+
+
+@pytest.mark.parametrize("B,L,parts", [(32, 8192, 8), (8, 32768, 8)])      # BASELINE configs[1] and configs[4] at their full per-GPU batch
+def test_full_batch_step_is_mean_of_sub_batches(dev, B, L, parts):
+    """The loss is a batch mean (models/diffusion/train.py:69-108: every term is `.mean()` over the batch), so the bf16 training step at
+    the bench's FULL batch must equal the mean of the steps on its equal-sized sub-batches with the same (t, x0) — loss, logged terms and
+    the whole gradient arena, segment by segment.  The sub-batch size (4 x 8192 / 1 x 32768) is the one the fp32 / directional-derivative
+    tests above validate; the full batch takes other GEMM split counts, grid sizes and XCD tile orders (M = 262,144)."""
+    import bench
+    tr = bench.make_trainer(dev, seed=31)
+    model = tr.diffusion
+    model.compute_dtype = torch.bfloat16
+    h, z, s, _ = bench.synthetic_batch(B, L, dev, seed=32)
+    g = torch.Generator(device=dev).manual_seed(33)
+    t = torch.rand(B, device=dev, generator=g) * 0.8 + 0.1
+    x0 = torch.randn(B, 6, L, device=dev, generator=g)
+    opt = tr.configure_optimizers()["optimizer"]
+
+    def step(sl):
+        opt.zero_grad()
+        loss, logs = tr(model, h[sl], z[sl], s[sl], None, t=t[sl], x0=x0[sl])
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: float(v) for k, v in logs.items()}, model.arena.grad.clone()
+
+    # sub-batches FIRST (and the full batch twice, below): their spread is the yardstick for what fp32-atomic ordering alone does
+    nb = B // parts
+    acc, losses, logsum = torch.zeros_like(model.arena.data, dtype=torch.float64), [], {}
+    for i in range(parts):
+        l, lg, gr = step(slice(i * nb, (i + 1) * nb))
+        acc += gr.double()
+        losses.append(l)
+        for k, v in lg.items():
+            logsum[k] = logsum.get(k, 0.0) + v / parts
+    mean_g = (acc / parts)
+    lf, logf, gf = step(slice(0, B))
+    lf2, _, gf2 = step(slice(0, B))
+    model.compute_dtype = None
+    assert math.isfinite(lf) and abs(lf - sum(losses) / parts) <= 2e-4 * abs(lf), (lf, losses)
+    for k in ("osl", "del"):
+        assert abs(logf[k] - logsum[k]) <= 5e-4 * abs(logsum[k]) + 1e-6, (k, logf[k], logsum[k])
+    noise = rel(gf2, gf)                      # run-to-run difference of the SAME full-batch step (atomics order)
+    worst = 0.0
+    for seg, (a, b) in model.arena.segments(model.args.backbone_args.depth).items():
+        e = rel(gf[a:b], mean_g[a:b])
+        worst = max(worst, e)
+        assert e < 3e-3, (seg, e, noise)
+    n_full, n_mean = float(gf.double().norm()), float(mean_g.norm())
+    assert abs(n_full - n_mean) <= 1e-3 * n_mean, (n_full, n_mean)
+    print(f"[B={B} L={L}] full batch vs mean of {parts} sub-batches: loss {lf:.6f} / {sum(losses) / parts:.6f}, |g| {n_full:.5f} / {n_mean:.5f}, "
+          f"worst segment rel-L2 {worst:.2e} (same step twice: {noise:.2e})")
 
 
 def test_sampler_graph_equals_eager_config3(dev):

@@ -115,3 +115,32 @@ def test_inference_artifact_roundtrip(dev, tmp_path):
     chart, _ = m.sample(fx["audio"].to(dev), fx["labels"].to(dev), int(fx["num_steps"]), s_init=fx["s_init"].to(dev),
                         x_init=fx["x_init"].to(dev))
     assert rel_l2(chart, fx["chart"]) < 1e-4
+
+
+def test_predict_entry(dev, tmp_path):
+    """`predict` (scripts/predict.py:56-77 between the audio decode and the .osz packaging): artifact + spectrogram + `--diff` rows ->
+    chart signals and labels, as a function and as `python -m osu_dreamer_amd predict`."""
+    import numpy as np
+    from osu_dreamer_amd import fit, predict as P
+    fx, ld, sd, dd = load("ldm_tiny")
+    hp, w = hparams(ld, sd, dd), weights(fx, ld, sd, dd)
+    ref = LDM(ldm_args_from_dict(hp))
+    ref.load_state_dict(w, strict=False)
+    art = str(tmp_path / "inference.pt")
+    torch.save({"hparams": hp, "state_dict": ref.state_dict()}, art)
+    spec = fx["audio"].numpy()
+    diffs = [[5.5, 9., 8., 4., 6.], [3.2, 7., 6., 4., 5.]]
+    sig, lab = P.predict(art, spec, diffs, sample_steps=3, device=str(dev), seed=7)
+    assert sig.shape == (2, 9, spec.shape[-1]) and lab.shape == (2, 5) and np.isfinite(sig).all()
+    # the same through the CLI
+    np.save(tmp_path / "song.spec.npy", spec)
+    out = str(tmp_path / "pred.npz")
+    argv = ["predict", "--model-path", art, "--spec", str(tmp_path / "song.spec.npy"), "--sample-steps", "3", "--seed", "7",
+            "--device", str(dev), "--out", out]
+    for d in diffs:
+        argv += ["--diff"] + [str(x) for x in d]
+    fit.main(argv)
+    z = np.load(out)
+    assert np.array_equal(z["pred_signals"], sig) and np.array_equal(z["pred_labels"], lab)
+    with pytest.raises(ValueError):
+        P.predict(art, spec, [[1., 2., 3.]], device=str(dev))

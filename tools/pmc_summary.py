@@ -69,4 +69,12 @@ if jpath:
     out["classes"] = {k: {"ms_per_step": round(v[0] / 1e3, 2), "hbm_GBps": round(v[1] / (v[0] * 1e-6) / 1e9, 0) if v[0] else 0,
                           "hbm_frac_of_8TBps": round(v[1] / (v[0] * 1e-6) / 8e12, 3) if v[0] else 0,
                           "mfma_busy": round(v[2] / v[0], 3) if v[0] else 0} for k, v in agg.items()}
+    try:      # which build these counters belong to: bench.py quotes the record only while the library it runs has the same hash
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from osu_dreamer_amd import _lib
+        out["kernel_src_sha"] = _lib.source_sha()
+    except Exception as e:
+        out["kernel_src_sha"] = None
+        print("could not read the library's source hash:", e)
     json.dump(out, open(jpath, "w"), indent=1)
