@@ -34,7 +34,7 @@ enum { OD_ACT_NONE = 0, OD_ACT_SILU = 1 };
 enum { OD_ERR_ARG = -1, OD_ERR_ALIGN = -2, OD_ERR_UNSUPPORTED = -3, OD_ERR_COMM = -4 };
 
 int od_version(void);
-/* 16 hex digits: hash of the kernel sources (csrc/*.hip, *.h, this header, extra compiler flags) the library was built from.
+/* 16 hex digits: hash of the kernel sources (every .hip and .h under csrc, this header, extra compiler flags) the library was built from.
  * Measurement records under profiles/ quote it; bench.py refuses a record taken on another build. */
 const char* od_build_source_sha(void);
 const char* od_error_string(int code);

@@ -838,6 +838,180 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
     }
 }
 
+// ======================================================================== dQ, bf16, head_dim 64, 32x32x16 MFMA
+// Round 3.  The two-wave-per-SIMD attention loops sit where the SIMD's issue port and its matrix pipe are both full (the 16x16x32 dQ loop:
+// 323 issues per wave and tile at ~4.5 cycles each against 96 x 16 MFMA cycles), so what pays is fewer ISSUES per flop: a 32x32x16 MFMA
+// does the work of two 16x16x32 for one issue slot.  Same formulation as flash_fwd32_kernel — S^T = K Q'^T with the query as the
+// accumulator COLUMN, the dS^T accumulators feeding dQ'^T += K^T dS^T directly through the key permutation that the K^T operand reproduces
+// with transpose reads of the SAME staged K tile.
+// Registers decide the rest: a lane-constant C operand (-lse, -delta) of a 32x32 tile is a 16-register splat, and two query blocks per wave
+// cannot afford two of them each.  So lse is taken out of the loop algebraically.  With n = round(lse') (lse' = lse * log2 e, q' = q * scale * log2 e):
+//     dS^T = 2^(S^T - lse') (dP^T - delta) = 2^(-frac) * 2^(S^T) * [ V (2^-n dO)^T - 2^-n delta ]
+// i.e. the dO fragments are multiplied by the power of two 2^-n ONCE at kernel entry (exact), the dP chain starts at -2^-n delta, the S
+// chain starts at the inline constant 0, and the remaining per-query factor 2^(n - lse') in [0.7, 1.42] goes to the dQ row at the end.
+// 2^(S^T) is not shifted by a row maximum here: |q'.k| has to stay below ~120 (87 nats; with RMS-normed q and k of head_dim 64 it is
+// bounded by 11.6 |w_q| |w_k|), beyond which the result is Inf/NaN — loudly, never silently wrong.
+#ifndef OD_DQ32_NQB
+#define OD_DQ32_NQB 2     // 32-query blocks per wave
+#endif
+template <int NW, int NQB>
+__global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dq32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                                 const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int lddo,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                 bf16_t* __restrict__ dq, int lddq, int B, int H, int L) {
+    using St = Stage<bf16_t, 64>;
+    constexpr int HD = 64, QB = NW * NQB * 32, STAGE = 2 * St::BYTES;
+    static_assert(NW == 4, "the K/V tiles are streamed as 2 + 2 one-KiB pieces per wave");
+    OD_DYN_SMEM(smem);   // 2 stages x (K row-major, V row-major), 16-byte slots swizzled by swz32
+    const int nqt = (L + QB - 1) / QB;
+    int qt, bh;
+    if (!attn_block_coords(nqt, B * H, qt, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
+    const int q0 = qt * QB + wave * NQB * 32;
+    const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
+    const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
+    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
+    const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
+    auto dma = [&](int kt, unsigned char* st) {
+        const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u, sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
+        od_buffer_lds16(rk, vk, sk, st + wave * 1024);
+        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
+        od_buffer_lds16(rv, vv, sv, st + St::BYTES + wave * 1024);
+        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + St::BYTES + (wave + 4) * 1024);
+    };
+    // Q'^T and (2^-n dO)^T fragments (B operands): column = query, k = 16 s4 + 8 hi + j
+    s16x8 fq[NQB][4], fdo[NQB][4];
+    f32x16_t dinit[NQB];
+    float fscale[NQB];
+    f32x16_t dqacc[NQB][2];
+#pragma unroll
+    for (int qi = 0; qi < NQB; qi++) {
+        int row = q0 + qi * 32 + c32; row = row < L ? row : L - 1;
+        const bf16_t* qp = q + ((size_t)b * L + row) * ldq + h * HD;
+        const bf16_t* dp = dout + ((size_t)b * L + row) * lddo + h * HD;
+        const float l2 = lse[((size_t)b * H + h) * L + row] * LOG2E;
+        const float n = rintf(l2);
+        const float e = od_exp2(-n);                       // a power of two: scaling by it is exact
+        fscale[qi] = od_exp2(n - l2) * LN2;                // dL/dq' -> dL/d(q * scale): the factor ln 2 of the pre-multiplied q
+        dinit[qi] = (f32x16_t)(-delta[((size_t)b * H + h) * L + row] * e);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            fq[qi][s4] = *(const s16x8*)(qp + s4 * 16 + hi * 8);
+            float t[8];
+            od_ld8(dp + s4 * 16 + hi * 8, t);
+            u32x4 w;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) w[jj] = od_pack_bf2(t[2 * jj] * e, t[2 * jj + 1] * e);
+            fdo[qi][s4] = __builtin_bit_cast(s16x8, w);
+        }
+        dqacc[qi][0] = (f32x16_t)(0.f); dqacc[qi][1] = (f32x16_t)(0.f);
+    }
+    const int nkt = (L + 63) / 64;
+    int offK[4], offT[2][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) offK[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);                 // + kb * 4096; V tile: + St::BYTES
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int e = 0; e < 2; e++)                                                                   // K^T chunk of the K tile; + 2048 per 16-key slab
+            offT[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+    OD_DRAIN_VMEM();
+    dma(0, smem);
+    OD_WAIT_VMCNT(0);
+    __syncthreads();
+
+    auto tile = [&](int kt, const unsigned char* st, unsigned char* st_next, auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        if (kt + 1 < nkt) dma(kt + 1, st_next);
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            s16x8 fds[NQB][2];
+            {
+                s16x8 fk[4], fv[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    fk[s4] = *(const s16x8*)(st + offK[s4] + kb * 4096);
+                    fv[s4] = *(const s16x8*)(st + St::BYTES + offK[s4] + kb * 4096);
+                }
+#pragma unroll
+                for (int qi = 0; qi < NQB; qi++) {
+                    f32x16_t sa = od_mma32(fk[0], fq[qi][0], (f32x16_t)(0.f));
+                    f32x16_t pa = od_mma32(fv[0], fdo[qi][0], dinit[qi]);
+#pragma unroll
+                    for (int s4 = 1; s4 < 4; s4++) { sa = od_mma32(fk[s4], fq[qi][s4], sa); pa = od_mma32(fv[s4], fdo[qi][s4], pa); }
+#if defined(OD_DQ32_PK)
+                    {     // A/B: the 16 products as packed multiplies
+                        f32x16_t pp;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) pp[r] = od_exp2(sa[r]);
+                        pa = pp * pa;
+                        sa = (f32x16_t)(1.f);
+                    }
+#define OD_DQ32_P(r) (pa[r])
+#else
+#define OD_DQ32_P(r) (od_exp2(sa[r]) * pa[r])
+#endif
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        u32x4 w;
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) {
+                            const int r0 = 8 * sl + 2 * jj;
+                            float d0 = OD_DQ32_P(r0), d1 = OD_DQ32_P(r0 + 1);
+                            if constexpr (MASKED) {      // ragged last tile only: keys >= L (their K / V rows read as zero, not as -inf)
+                                if (kt * 64 + kb * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * hi >= L) d0 = 0.f;
+                                if (kt * 64 + kb * 32 + ((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2) + 4 * hi >= L) d1 = 0.f;
+                            }
+                            w[jj] = od_pack_bf2(d0, d1);
+                        }
+                        fds[qi][sl] = __builtin_bit_cast(s16x8, w);
+                    }
+                }
+            }
+            // dQ'^T += K^T dS^T : A = K^T fragment (rows = features of block db), two transpose reads per 16-key slab
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    const s16x4 a0 = od_lds_tr_read((const bf16_t*)(st + offT[db][0] + (kb * 2 + sl) * 2048));
+                    const s16x4 a1 = od_lds_tr_read((const bf16_t*)(st + offT[db][1] + (kb * 2 + sl) * 2048));
+                    s16x8 fkt;
+                    fkt[0] = a0[0]; fkt[1] = a0[1]; fkt[2] = a0[2]; fkt[3] = a0[3];
+                    fkt[4] = a1[0]; fkt[5] = a1[1]; fkt[6] = a1[2]; fkt[7] = a1[3];
+#pragma unroll
+                    for (int qi = 0; qi < NQB; qi++) dqacc[qi][db] = od_mma32(fkt, fds[qi][sl], dqacc[qi][db]);
+                }
+        }
+        OD_WAIT_VMCNT(0);
+        __syncthreads();
+    };
+    unsigned char* const s0 = smem;
+    unsigned char* const s1 = smem + STAGE;
+    const int nfull = L / 64;
+    int kt = 0;
+    for (; kt + 1 < nfull; kt += 2) {
+        tile(kt, s0, s1, std::false_type{});
+        tile(kt + 1, s1, s0, std::false_type{});
+    }
+    if (kt < nfull) { if (kt & 1) tile(kt, s1, s0, std::false_type{}); else tile(kt, s0, s1, std::false_type{}); kt++; }
+    if (nfull < nkt) { if (kt & 1) tile(kt, s1, s0, std::true_type{}); else tile(kt, s0, s1, std::true_type{}); }
+#pragma unroll
+    for (int qi = 0; qi < NQB; qi++) {
+        const int row = q0 + qi * 32 + c32;
+        if (row < L) {
+            bf16_t* drow = dq + ((size_t)b * L + row) * lddq + h * HD;
+            const float f = fscale[qi];
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+                    st4(drow + db * 32 + 8 * t4 + 4 * hi, dqacc[qi][db][4 * t4] * f, dqacc[qi][db][4 * t4 + 1] * f,
+                        dqacc[qi][db][4 * t4 + 2] * f, dqacc[qi][db][4 * t4 + 3] * f);
+        }
+    }
+}
+
 #ifndef OD_ATTN_NW
 #define OD_ATTN_NW 4      // waves per workgroup of the bf16 forward / dQ kernels.  6 (K/V streamed once per 192 queries) measured 0.71x: a 6-wave group lands 2,2,1,1 on the SIMDs and a second group no longer fits at 3 waves/SIMD
 #endif
@@ -880,6 +1054,19 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     const int gk = attn_grid((L + 16 * NWK * NK - 1) / (16 * NWK * NK), B * H);
     OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale);
+#ifndef OD_DQ32
+#define OD_DQ32 0        // 1 = the 32x32x16 dQ kernel above for bf16 / head_dim 64 / pre-multiplied q.  Measured (profiles/r03a_ab_attn.txt, same box,
+                         // backward of one layer): 16x16x32 kernel 24.10 / 24.12 ms, this one 24.45 / 24.37 ms (one query block per wave: 26.0 / 25.6) —
+                         // halving the MFMA issue count does not pay here either (round 2 saw the same for dK/dV), so it is kept as a variant only
+#endif
+    if constexpr (OD_DQ32 && std::is_same<T, bf16_t>::value && HD == 64 && PRE) {
+        constexpr int NQB = OD_DQ32_NQB;
+        const int gq32 = attn_grid((L + 4 * NQB * 32 - 1) / (4 * NQB * 32), B * H);
+        OD_LAUNCH_DYN((flash_bwd_dq32_kernel<4, NQB>), dim3(gq32), dim3(256), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                      (const bf16_t*)v, ldv, (const bf16_t*)dout, lddo, lse, (const float*)delta, (bf16_t*)dq, lddq, B, H, L);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr int NWQ = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
     const int gq = attn_grid((L + 16 * NQ * NWQ - 1) / (16 * NQ * NWQ), B * H);
     OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,

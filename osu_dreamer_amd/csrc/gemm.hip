@@ -510,7 +510,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
         // of the G slab and 4 of the A slab; rows past this block's M range read as zero (the descriptors end at row `me`), columns
         // past N / K inside a row bring in neighbouring data that only reaches outputs the epilogue drops.
         const int uw = od_uniform(wave);
-        const long availg = (long)(me - mb - 1) * ldg + (N - n0), availa = (long)(me - mb - 1) * lda + (K - k0);
+        // the descriptors end after the last valid column of row me-1, rounded UP to a whole 16-byte chunk (ld is a multiple of 8 elements, so
+        // the chunk lies inside the row): the hardware checks the range per DWORD, and an odd width (Hf = 1365) would otherwise lose the last
+        // column of that row
+        const long availg = (long)(me - mb - 1) * ldg + ((N - n0 + 7) & ~7), availa = (long)(me - mb - 1) * lda + ((K - k0 + 7) & ~7);
         const od_srd_t srdg = od_make_srd(G + (size_t)mb * ldg + n0, (unsigned)((availg > 0 ? availg : 0) * 2));
         const od_srd_t srda = od_make_srd(A + (size_t)mb * lda + k0, (unsigned)((availa > 0 ? availa : 0) * 2));
         unsigned vg[4], va[4];
@@ -650,13 +653,24 @@ __device__ __forceinline__ void tn512_frag(od_frag<bf16_t>& f, const unsigned ch
 }
 __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A, int lda,
                                                              float* __restrict__ dW, int lddw, float* __restrict__ dbias,
-                                                             int M, int N, int K, int m_per_block, int xcd_order) {
+                                                             int M, int N, int K, int m_per_block, int xcd_full) {
+    const int xcd_order = xcd_full & 3;
     constexpr int STG = 65536;                 // G slab [64][256] 32 KiB + A slab [64][256] 32 KiB
     OD_DYN_SMEM(smem);
     float* sred = (float*)(smem + 2 * STG);    // 256 floats
     const int tiles_n = (N + 255) / 256, tiles_k = (K + 255) / 256;
     int tile, split;
-    if (xcd_order) {
+    if (xcd_order == 2) {
+        // "packed" order (block b runs on XCD b % 8): the (split, tile) items, split-major, are cut into 8 consecutive runs, one per XCD, so
+        // the tiles of one M-split — which stream the same G / A rows — sit on ONE XCD and share them through its L2, with the FEWEST
+        // M-splits that fill the chip (m_per_block is as long as possible: every split costs N x K fp32 atomics in the epilogue, and at
+        // 340 G atomics/s chip-wide a workgroup's 65,536 of them take ~49 us).  xcd_order = per_xcd << 2 | 2.
+        const int per_xcd = xcd_full >> 2;
+        const int gi = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= per_xcd) return;
+        split = gi / (tiles_n * tiles_k);
+        tile = gi % (tiles_n * tiles_k);
+    } else if (xcd_order) {
         // XCD-aware order (block b runs on XCD b % 8): ALL output tiles of one M-split run on one XCD, side by side, so the G / A
         // row slabs they stream are fetched from HBM once and re-read from that XCD's L2 by the other tiles of the split.  (With
         // the tile index fastest the tiles of a split were dealt over all 8 XCDs: 3.16 GB of fetches for 1.9 GB of operands on
@@ -693,7 +707,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
     const bool isa = wave >= 4;
     const int ld = isa ? lda : ldg, c0 = isa ? k0 : n0, width = isa ? K : N;
     const bf16_t* opnd = (isa ? A : G) + (size_t)mb * ld + c0;
-    const long avail = (long)(me - mb - 1) * ld + (width - c0);           // elements from `opnd` to the end of row me-1
+    // elements from `opnd` to the end of row me-1, the last row's width rounded UP to a whole 16-byte chunk (inside the row: ld % 8 == 0):
+    // the hardware range-checks per dword, and an odd width (Hf = 1365) would otherwise lose the last column of that row
+    const long avail = (long)(me - mb - 1) * ld + ((width - c0 + 7) & ~7);
     const od_srd_t srd = od_make_srd(opnd, (unsigned)((avail > 0 ? avail : 0) * 2));
     unsigned voff[8];
 #pragma unroll
@@ -753,6 +769,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
         if (tid < 256 && n0 + tid < N) atomicAdd(dbias + n0 + tid, sred[tid]);
     }
 }
+
+// (Round 3 also measured a 4-deep ring of 32-row slabs — three stages = 96 KiB in flight per CU, counted vmcnt, one bare barrier per stage —
+// in place of the two 64-row stages: identical within +-1 % on every shape, profiles/r03d_ab_gemm_tn.txt.  Like the NT kernel, this loop is
+// not waiting for one slab's latency; its DMA skeleton and its MFMA + transpose-read skeleton each run at ~1.05 PF/s on their own.  Removed.)
 
 // column sums (bias gradients): out[n] += sum_m G[m][n]
 template <class T>
@@ -835,9 +855,18 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
 #ifndef OD_TN_XCD_MIN_TILES
 #define OD_TN_XCD_MIN_TILES 16
 #endif
-            const int xcd_order = tiles2 >= OD_TN_XCD_MIN_TILES;
+            static const int xcd_min_tiles = od_env_int("OD_TN_XCD_MIN_TILES", OD_TN_XCD_MIN_TILES);
+            static const int eff_pct = od_env_int("OD_TN_EFF_PCT", 100);      // take the SMALLEST k whose fill efficiency reaches this
+            // packed order (round 3) below `xcd_min_tiles` output tiles; from there on the round-2 order (8 k splits, whole splits per XCD, several
+            // block rounds), which still wins on the 24-tile qkv shape (777 vs 750 TF/s).  OD_TN_PACK=0 / 2: never / always packed (A/B).
+            static const int pack_mode = od_env_int("OD_TN_PACK", 1);
+            int xcd_order = tiles2 >= xcd_min_tiles;
+            const bool pack = pack_mode == 2 || (pack_mode == 1 && !xcd_order);
             int sp, grid_tn;
-            if (xcd_order) {
+            if (pack) {
+                // fewest M-splits that fill the chip, whole splits side by side on an XCD (see the kernel): tiles2 x sp <= 256 workgroups
+                sp = OD_TN_BLOCKS / tiles2 > 0 ? OD_TN_BLOCKS / tiles2 : 1;
+            } else if (xcd_order) {
                 // M-splits = 8 k: each XCD (32 CUs, one workgroup each) holds k splits x tiles2 tiles; pick the k whose k * tiles2 fills
                 // whole waves of 32 workgroups best (qkv: 24 tiles -> k = 4 -> 96 = 3 x 32)
                 int best_k = 1; double best_eff = 0.0;
@@ -845,7 +874,10 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
                     const int bpx = kk * tiles2, waves = (bpx + 31) / 32;
                     const double eff = (double)bpx / (waves * 32);
                     if (eff > best_eff + 1e-9) { best_eff = eff; best_k = kk; }
+                    if (eff * 100.0 >= eff_pct - 1e-9) { best_k = kk; break; }
                 }
+                static const int force_k = od_env_int("OD_TN_KK", 0);                // A/B: M-splits per XCD given outright
+                if (force_k > 0) best_k = force_k;
                 sp = 8 * best_k;
             } else {
                 sp = OD_TN_BLOCKS >= 512 ? (OD_TN_BLOCKS + tiles2 - 1) / tiles2 : (OD_TN_BLOCKS / tiles2 > 0 ? OD_TN_BLOCKS / tiles2 : 1);
@@ -853,7 +885,12 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
             int mpb2 = (M + sp - 1) / sp;
             mpb2 = ((mpb2 + 63) / 64) * 64;
             sp = (M + mpb2 - 1) / mpb2;
-            grid_tn = xcd_order ? ((sp + 7) / 8) * 8 * tiles2 : tiles2 * sp;
+            if (pack) {
+                const int per_xcd = (tiles2 * sp + 7) / 8;
+                xcd_order = (per_xcd << 2) | 2;
+                grid_tn = per_xcd * 8;
+            } else
+                grid_tn = xcd_order ? ((sp + 7) / 8) * 8 * tiles2 : tiles2 * sp;
             OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(grid_tn), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order);
             OD_CHECK_LAUNCH();
             return 0;

@@ -225,6 +225,26 @@ def test_gemm_tn_colsum(dev, dtype, M, N, K):
     assert rel_l2(out, Gf.float().cpu()[:, :N].sum(0)) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 1365), (257, 1365, 512), (777, 261, 1365)])
+def test_gemm_tn_odd_width_counts_every_row(dev, M, N, K):
+    """Hf = 1365 is odd: the last valid column shares a dword with the first padding column, and the buffer descriptor of each
+    M-split ends at its last row.  Hardware range-checks per dword, so a descriptor cut at the exact element count drops that
+    column of the split's last row.  Integer-valued operands make the loss exact: every row must be counted."""
+    bf = torch.bfloat16
+    lda, ldg = (K + 7) // 8 * 8, (N + 7) // 8 * 8
+    A = torch.zeros(M, lda, dtype=bf, device=dev)
+    G = torch.zeros(M, ldg, dtype=bf, device=dev)
+    A[:, K - 1] = 1.0
+    A[:, 0] = 2.0
+    G[:, N - 1] = 1.0
+    G[:, 0] = 1.0
+    dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    ops.gemm_tn(G, A, dW, n_cols=N, k_cols=K, dbias=db)
+    dW = dW.cpu()
+    assert float(dW[N - 1, K - 1]) == M and float(dW[0, K - 1]) == M and float(dW[N - 1, 0]) == 2 * M and float(dW[0, 0]) == 2 * M
+    assert float(db.cpu()[N - 1]) == M and float(dW.sum()) == 6 * M
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(40000, 3072, 512), (33001, 1365, 512), (65536, 512, 1365), (32768, 512, 1024), (50001, 136, 512)])
 def test_gemm_tn_large_m(M, N, K):
@@ -418,7 +438,7 @@ def test_rmsnorm_gate_residual_film_equals_pair(dev, dtype, C, with_cl):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,L,hd", [(1, 2, 150, 32), (2, 1, 64, 64), (1, 1, 257, 64), (1, 1, 5, 32)])
+@pytest.mark.parametrize("B,H,L,hd", [(1, 2, 150, 32), (2, 1, 64, 64), (1, 1, 257, 64), (1, 1, 5, 32), (2, 2, 40, 64), (1, 2, 321, 64)])
 def test_flash_attention(dev, dtype, B, H, L, hd):
     g = torch.Generator().manual_seed(8)
     M, dh = B * L, H * hd

@@ -50,6 +50,7 @@ def child():
           " ".join(f"{k}={v:.1e}" for k, v in errs.items()), flush=True)
 
 if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     if os.environ.get("AB_CHILD"):
         child()
     else:
@@ -58,7 +59,9 @@ if __name__ == "__main__":
         libs = args or [os.path.join("osu_dreamer_amd", "libosudreamer_hip.so")]
         for rd in range(rounds):
             for lib in libs:
-                env = dict(os.environ, AB_CHILD="1", OSU_DREAMER_HIP_LIB=os.path.abspath(lib))
+                from ab_common import parse
+                label, libpath, extra = parse(lib)
+                env = dict(os.environ, AB_CHILD="1", OSU_DREAMER_HIP_LIB=libpath, **extra)
                 out = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True, timeout=600)
                 line = [l for l in out.stdout.splitlines() if l.startswith("fwd")]
-                print(f"[round {rd}] {os.path.basename(lib):32s} " + (line[0] if line else "FAILED: " + out.stderr[-400:]), flush=True)
+                print(f"[round {rd}] {label:44s} " + (line[0] if line else "FAILED: " + out.stderr[-400:]), flush=True)

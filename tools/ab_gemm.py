@@ -22,14 +22,24 @@ def child():
         err = float((C[rows].float() - ref).norm() / ref.norm())
         t = timeit(lambda: ops.gemm_nt(A, W, bias, C), 10)
         out.append(f"{name} {2.0 * M * N * K / t / 1e9:6.0f}{'' if err < 5e-3 else ' WRONG(%.1e)' % err}")
-    for name, N, K in (("w_qkv", 3072, 512), ("w_out", 512, 1024), ("w_vg", 1365, 512), ("w_proj_o", 512, 1365)):
-        Gm, A = r(M, (N + 7) // 8 * 8), r(M, (K + 7) // 8 * 8)
+    # weight gradients in the model's own layouts: the two halves of d_vg are column ranges of one [M, 2816] tensor, hh is [M, 1408]
+    Hf, Hp = 1365, 1408
+    dvg = r(M, 2 * Hp)
+    for name, Gm, A, N, K in (("w_qkv", r(M, 3072), r(M, 512), 3072, 512), ("w_out", r(M, 512), r(M, 1024), 512, 1024),
+                              ("w_vg", dvg[:, Hp:], r(M, 512), Hf, 512), ("w_proj_o", r(M, 512), r(M, Hp), 512, Hf)):
         dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        ops.gemm_tn(Gm, A, dW, n_cols=N, k_cols=K, dbias=db)
+        ref = Gm[:, :N].float().t() @ A[:, :K].float()
+        err = float((dW - ref).norm() / ref.norm())
+        bref = Gm[:, :N].float().sum(0)
+        errb = float((db - bref).norm() / bref.norm())
+        del ref
         t = timeit(lambda: ops.gemm_tn(Gm, A, dW, n_cols=N, k_cols=K, dbias=db), 10)
-        out.append(f"{name} {2.0 * M * N * K / t / 1e9:6.0f}")
+        out.append(f"{name} {2.0 * M * N * K / t / 1e9:6.0f}{'' if max(err, errb) < 3e-3 else ' WRONG(%.1e,%.1e)' % (err, errb)}")
     print("TF/s: " + " | ".join(out), flush=True)
 
 if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     if os.environ.get("AB_CHILD"):
         child()
     else:
@@ -37,7 +47,9 @@ if __name__ == "__main__":
         rounds = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--rounds=")), 2))
         for rd in range(rounds):
             for lib in libs:
-                env = dict(os.environ, AB_CHILD="1", OSU_DREAMER_HIP_LIB=os.path.abspath(lib))
+                from ab_common import parse
+                label, libpath, extra = parse(lib)
+                env = dict(os.environ, AB_CHILD="1", OSU_DREAMER_HIP_LIB=libpath, **extra)
                 o = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True, timeout=900)
                 line = [l for l in o.stdout.splitlines() if l.startswith("TF/s")]
-                print(f"[round {rd}] {os.path.basename(lib):28s} " + (line[0] if line else "FAILED: " + o.stderr[-400:]), flush=True)
+                print(f"[round {rd}] {label:44s} " + (line[0] if line else "FAILED: " + o.stderr[-400:]), flush=True)

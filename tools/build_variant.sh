@@ -17,6 +17,6 @@ for s in gemm rowops misc heads optim attn style latent comm; do
     objs="$objs build/$s.o"
   fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -ldl -o $out/libod_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs build/version.o -ldl -o $out/libod_$name.so
 rm -rf $out/obj_$name
 echo built $out/libod_$name.so
