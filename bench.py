@@ -148,11 +148,11 @@ def roofline_of_dominant_kernel(tr, B, L):
     H, hd, dh = eng.H, eng.hd, eng.dh
     i = eng.depth - 1
     qk, qkv, y, lse = t[f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
-    dy, dqk, dqkv, delta = t["d.y"], t["d.qk"], t["d.qkv"], t["d.delta"]
+    dy, dqkv, delta = t["d.y"], t["d.qkv"], t["d.delta"]
     scale = 1 / math.sqrt(hd)
 
     def bwd():
-        eng.attn_bwd_launch(qk, qkv, y, dy, lse, delta, dqk, dqkv)       # exactly as the step launches it
+        eng.attn_bwd_launch(i, dy, delta, dqkv)       # exactly as the step launches it (q / k norm + RoPE backward in its epilogues)
 
     def fwd():
         ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, H, L, hd, scale, q_prescaled=True)
@@ -163,7 +163,7 @@ def roofline_of_dominant_kernel(tr, B, L):
     ach_bwd = BWD_PASSES_ALGORITHMIC * unit / t_bwd / 1e12
     ach_fwd = 2 * unit / t_fwd / 1e12
     return {
-        "bound": "mfma", "kernel": "od_flash_attn_bwd (attention backward of one layer)",
+        "bound": "mfma", "kernel": "od_flash_attn_bwd_qkrope (attention backward of one layer, q/k norm + RoPE backward in its epilogues)",
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "ms_per_launch": round(t_bwd * 1e3, 3),

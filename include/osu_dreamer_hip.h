@@ -139,6 +139,15 @@ int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* k, int ldk,
 int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                       int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk,
                       int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled, void* stream);
+/* od_flash_attn_bwd and od_qk_norm_rope_bwd in one: q, k are the normed + rotated operands, qkv the PRE-norm projection [M, 3*H*hd]
+ * (q | k | v column blocks; v is read from it), dqkv [M, 3*H*hd] receives the gradient of that projection (the backward of the norm + RoPE
+ * runs on the dQ / dK accumulators in the attention kernels' epilogues: dq and dk never exist in memory), dwq / dwk [hd] += the norm weight
+ * gradients.  bf16, head_dim 64 only (OD_ERR_UNSUPPORTED otherwise: call the two entry points above).
+ * replaces: autograd of attn.py:74-82. */
+int od_flash_attn_bwd_qkrope(int dtype, const void* q, int ldq, const void* k, int ldk, const void* qkv, int ldqkv, const void* o,
+                             int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dqkv, int lddqkv,
+                             const float* wq, const float* wk, const float* table, float* dwq, float* dwk, int B, int H, int L,
+                             int hd, float scale, float eps, float q_scale, int q_prescaled, void* stream);
 /* L x L x hd MFMA passes one od_flash_attn_bwd call issues for bf16 (the algorithmic minimum with the score recompute is 5);
  * bench.py reports it next to the algorithmic roofline figure. */
 int od_flash_attn_bwd_passes(void);

@@ -532,15 +532,87 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
     }
 }
 
+// ---- backward of the q / k RMSNorm + RoPE (attn.py:77-81) applied to the dQ / dK accumulators in the attention kernels' epilogues
+// (round 3; bf16, head_dim 64).  The separate od_qk_norm_rope_bwd pass read dq, dk (M x 2*H*hd) and the pre-norm q, k and wrote the
+// gradient of the qkv projection: 3.2 GB per layer at 4.8 TB/s = 0.67 ms.  In the epilogue the gradient row is already in registers
+// (fp32, not yet rounded), a lane holds features 16 dt + 4 g + r of its row — the rotary partner d +- 32 is accumulator tile dt ^ 2 of
+// the same lane, the row's sums over 64 features are 16 in-lane terms and two shuffles — and only the pre-norm row is read.
+struct RopeBwdEpi {
+    const bf16_t* pre; int ldpre;      // pre-norm q (resp. k) columns of the qkv projection: row m, head h at pre[m * ldpre + h * 64]
+    const float* w;                    // nn.RMSNorm weight [64]
+    const float* table;                // (cos, sin) [L][32][2]
+    float* dw;                         // += gradient of w
+    float eps, gs;                     // gs: the factor the forward multiplied its output by (q: q_scale, k: 1)
+};
+// a[dt][r]: gradient wrt the normed + rotated (+ scaled) row, feature 16 dt + 4 g + r.  Stores the gradient wrt the pre-norm row to `out`
+// (if valid) and adds this row's share of the weight gradient to dwacc.  Must be called by all 64 lanes (shuffles).
+__device__ __forceinline__ void qk_rope_norm_bwd_row(const f32x4 (&a)[4], const RopeBwdEpi& rb, long m, int l, int h, int g, bool valid,
+                                                     bf16_t* out, f32x4 (&dwacc)[4]) {
+    const bf16_t* xr = rb.pre + m * rb.ldpre + h * 64 + 4 * g;
+    float xv[4][4], ss = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        const u32x2 raw = *(const u32x2*)(xr + dt * 16);
+        union { uint32_t u; float f; } c0, c1, c2, c3;
+        c0.u = raw[0] << 16; c1.u = raw[0] & 0xffff0000u; c2.u = raw[1] << 16; c3.u = raw[1] & 0xffff0000u;
+        xv[dt][0] = c0.f; xv[dt][1] = c1.f; xv[dt][2] = c2.f; xv[dt][3] = c3.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) ss += xv[dt][r] * xv[dt][r];
+    }
+    ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+    const float inv = rsqrtf(ss * (1.f / 64.f) + rb.eps);
+    float cs[2][4], sn[2][4];
+#pragma unroll
+    for (int dl = 0; dl < 2; dl++) {
+        float t[8];
+        od_ld8(rb.table + ((size_t)l * 32 + dl * 16 + 4 * g) * 2, t);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { cs[dl][r] = t[2 * r]; sn[dl][r] = t[2 * r + 1]; }
+    }
+    float dy[4][4], xh[4][4], dot = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        const f32x4 wv = *(const f32x4*)(rb.w + dt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float d = valid ? a[dt][r] * rb.gs : 0.f, dp = valid ? a[dt ^ 2][r] * rb.gs : 0.f;
+            const float u = d * cs[dt & 1][r] + dp * (dt < 2 ? sn[dt & 1][r] : -sn[dt & 1][r]);      // un-rotation
+            xh[dt][r] = xv[dt][r] * inv;
+            dwacc[dt][r] += u * xh[dt][r];
+            dy[dt][r] = u * wv[r];
+            dot += dy[dt][r] * xh[dt][r];
+        }
+    }
+    dot += __shfl_xor(dot, 16); dot += __shfl_xor(dot, 32);
+    dot *= (1.f / 64.f);
+    if (valid) {
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+            st4(out + dt * 16 + 4 * g, inv * (dy[dt][0] - xh[dt][0] * dot), inv * (dy[dt][1] - xh[dt][1] * dot),
+                inv * (dy[dt][2] - xh[dt][2] * dot), inv * (dy[dt][3] - xh[dt][3] * dot));
+    }
+}
+// the wave's weight-gradient partials: sum over the 16 rows (lanes x) of each feature group g, 64 atomics per wave
+__device__ __forceinline__ void qk_rope_norm_bwd_dw(f32x4 (&dwacc)[4], float* dw, int x, int g) {
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = dwacc[dt][r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (x == 0) atomicAdd(dw + dt * 16 + 4 * g + r, v);
+        }
+}
+
 // dK, dV: block owns 4 waves x NK*16 keys; loop over 64-query tiles.
 //   S = Q K^T (cols = keys) ; dV^T += dO^T P ; dP = dO V^T ; dS = P*(dP - delta)*scale ; dK^T += Q^T dS
 // LDS per stage: Q, dO row-major (+ Q^T, dO^T for f32); bf16 double-buffers the stage.
-template <class T, int HD, int NK, int NWK, bool PRE>
+template <class T, int HD, int NK, int NWK, bool PRE, bool RB = false>
 __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                                const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                T* __restrict__ dk, int lddk, T* __restrict__ dv, int lddv,
-                                                               int B, int H, int L, float scale) {
+                                                               int B, int H, int L, float scale, RopeBwdEpi rb) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32, ND = HD / 16, KB = NWK * NK * 16;
     static_assert(NWK == 4 || St::TR, "the register-staged (f32) path assumes 256 threads");
@@ -694,6 +766,29 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
     const int nfull = kragged ? 0 : L / 64;
     for (int qt = 0; qt < nfull; qt++) tile(qt, std::false_type{});
     for (int qt = nfull; qt < nqt; qt++) tile(qt, std::true_type{});
+    if constexpr (RB) {
+        // dV as it is; dK through the backward of k's RMSNorm + RoPE, straight into the qkv projection's gradient
+        f32x4 dwacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) dwacc[dt] = (f32x4)(0.f);
+#pragma unroll
+        for (int ki = 0; ki < NK; ki++) {
+            const int row = key0 + ki * 16 + x;
+            const bool valid = row < L;
+            const int rc = valid ? row : L - 1;
+            if (valid) {
+                T* dvr = dv + ((size_t)b * L + row) * lddv + h * HD;
+#pragma unroll
+                for (int dt = 0; dt < ND; dt++) st4(dvr + dt * 16 + 4 * g, dvacc[ki][dt][0], dvacc[ki][dt][1], dvacc[ki][dt][2], dvacc[ki][dt][3]);
+            }
+            f32x4 a[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) a[dt] = dkacc[ki][dt < ND ? dt : 0] * out_scale;
+            qk_rope_norm_bwd_row(a, rb, (long)b * L + rc, rc, h, g, valid, (bf16_t*)dk + ((size_t)b * L + rc) * lddk + h * HD, dwacc);
+        }
+        qk_rope_norm_bwd_dw(dwacc, rb.dw, x, g);
+        return;
+    }
 #pragma unroll
     for (int ki = 0; ki < NK; ki++) {
         const int row = key0 + ki * 16 + x;
@@ -712,11 +807,11 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
 
 // dQ: block owns 4 waves x NQ*16 queries; loop over 64-key tiles.
 //   S^T = K Q^T ; dP^T = V dO^T ; dS^T = P^T*(dP^T - delta)*scale ; dQ^T += K^T dS^T
-template <class T, int HD, int NQ, int NW, bool PRE>
+template <class T, int HD, int NQ, int NW, bool PRE, bool RB = false>
 __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                               const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              T* __restrict__ dq, int lddq, int B, int H, int L, float scale) {
+                                                              T* __restrict__ dq, int lddq, int B, int H, int L, float scale, RopeBwdEpi rb) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32, ND = HD / 16, QB = NW * NQ * 16;
     constexpr int NSTAGE = St::TR ? 2 : 1;
@@ -824,6 +919,23 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
     const int nfull = L / 64;
     for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
     if (nfull < nkt) tile(nfull, std::true_type{});
+    if constexpr (RB) {
+        f32x4 dwacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) dwacc[dt] = (f32x4)(0.f);
+#pragma unroll
+        for (int qi = 0; qi < NQ; qi++) {
+            const int row = q0 + qi * 16 + x;
+            const bool valid = row < L;
+            const int rc = valid ? row : L - 1;
+            f32x4 a[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) a[dt] = dqacc[qi][dt < ND ? dt : 0] * out_scale;
+            qk_rope_norm_bwd_row(a, rb, (long)b * L + rc, rc, h, g, valid, (bf16_t*)dq + ((size_t)b * L + rc) * lddq + h * HD, dwacc);
+        }
+        qk_rope_norm_bwd_dw(dwacc, rb.dw, x, g);
+        return;
+    }
 #pragma unroll
     for (int qi = 0; qi < NQ; qi++) {
         const int row = q0 + qi * 16 + x;
@@ -1043,8 +1155,12 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 template <class T, int HD, int NK, int NQ, bool PRE>
 int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout,
                int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H,
-               int L, float scale, hipStream_t st) {
+               int L, float scale, hipStream_t st, const RopeBwdEpi* rbq = nullptr, const RopeBwdEpi* rbk = nullptr) {
     const long M = (long)B * L;
+    constexpr bool CAN_RB = std::is_same<T, bf16_t>::value && HD == 64;
+    const bool use_rb = CAN_RB && rbq && rbk;
+    if ((rbq || rbk) && !use_rb) return OD_ERR_UNSUPPORTED;
+    const RopeBwdEpi none{};
     OD_LAUNCH((attn_delta_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)o, ldo, (const T*)dout, lddo, delta,
               B, H, L, HD);
 #ifndef OD_DKV_NW
@@ -1052,13 +1168,21 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 #endif
     constexpr int NWK = Stage<T, HD>::TR ? OD_DKV_NW : 4;
     const int gk = attn_grid((L + 16 * NWK * NK - 1) / (16 * NWK * NK), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
-              (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale);
+#define OD_LAUNCH_DYN_X(...) OD_LAUNCH_DYN(__VA_ARGS__)      /* lets an argument-list macro expand first */
+#define DKV_ARGS dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
+              (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale
+    if constexpr (CAN_RB) {
+        if (use_rb) OD_LAUNCH_DYN_X((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE, true>), DKV_ARGS, *rbk);
+        else OD_LAUNCH_DYN_X((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), DKV_ARGS, none);
+    } else
+        OD_LAUNCH_DYN_X((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), DKV_ARGS, none);
+#undef DKV_ARGS
 #ifndef OD_DQ32
 #define OD_DQ32 0        // 1 = the 32x32x16 dQ kernel above for bf16 / head_dim 64 / pre-multiplied q.  Measured (profiles/r03a_ab_attn.txt, same box,
                          // backward of one layer): 16x16x32 kernel 24.10 / 24.12 ms, this one 24.45 / 24.37 ms (one query block per wave: 26.0 / 25.6) —
                          // halving the MFMA issue count does not pay here either (round 2 saw the same for dK/dV), so it is kept as a variant only
 #endif
+    if (OD_DQ32 && use_rb) return OD_ERR_UNSUPPORTED;      // the 32x32 variant has no norm + RoPE epilogue
     if constexpr (OD_DQ32 && std::is_same<T, bf16_t>::value && HD == 64 && PRE) {
         constexpr int NQB = OD_DQ32_NQB;
         const int gq32 = attn_grid((L + 4 * NQB * 32 - 1) / (4 * NQB * 32), B * H);
@@ -1069,8 +1193,14 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     }
     constexpr int NWQ = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
     const int gq = attn_grid((L + 16 * NQ * NWQ - 1) / (16 * NQ * NWQ), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
-              (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale);
+#define DQ_ARGS dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
+              (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale
+    if constexpr (CAN_RB) {
+        if (use_rb) OD_LAUNCH_DYN_X((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE, true>), DQ_ARGS, *rbq);
+        else OD_LAUNCH_DYN_X((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), DQ_ARGS, none);
+    } else
+        OD_LAUNCH_DYN_X((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), DQ_ARGS, none);
+#undef DQ_ARGS
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -1093,6 +1223,12 @@ extern "C" int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* 
     return OD_ERR_UNSUPPORTED;
 }
 
+#ifndef OD_BWD_NK
+#define OD_BWD_NK 3
+#endif
+#ifndef OD_BWD_NQ
+#define OD_BWD_NQ 4
+#endif
 extern "C" int od_flash_attn_bwd_passes(void) { return 7; }   // dK/dV kernel: S, dP, dV, dK; dQ kernel: S, dP, dQ
 
 extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
@@ -1120,4 +1256,25 @@ extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* 
 #undef BWD
 #undef ARGS
     return OD_ERR_UNSUPPORTED;
+}
+
+// The backward of attention AND of the q / k RMSNorm + RoPE in front of it (attn.py:77-82), for a fused qkv projection: q', k' are the
+// normed + rotated operands the forward attended with, `qkv` holds the PRE-norm projection [M, 3*H*hd] (q | k | v column blocks), and
+// dqkv receives the gradient of that projection directly — dq and dk never exist in memory.  bf16, head_dim 64 only.
+extern "C" int od_flash_attn_bwd_qkrope(int dtype, const void* q, int ldq, const void* k, int ldk, const void* qkv, int ldqkv, const void* o,
+                                        int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dqkv, int lddqkv,
+                                        const float* wq, const float* wk, const float* table, float* dwq, float* dwk, int B, int H, int L,
+                                        int hd, float scale, float eps, float q_scale, int q_prescaled, void* stream) {
+    if (dtype != OD_BF16 || hd != 64) return OD_ERR_UNSUPPORTED;
+    if (!qkv || !dqkv || !wq || !wk || !table || !dwq || !dwk) return OD_ERR_ARG;
+    if (ldq % 8 || ldk % 8 || ldqkv % 8 || ldo % 8 || lddo % 8 || lddqkv % 8) return OD_ERR_ALIGN;
+    const int dh = H * hd;
+    const bf16_t* pre = (const bf16_t*)qkv;
+    bf16_t* g = (bf16_t*)dqkv;
+    const RopeBwdEpi rbq{pre, ldqkv, wq, table, dwq, eps, q_scale}, rbk{pre + dh, ldqkv, wk, table, dwk, eps, 1.f};
+    hipStream_t st = (hipStream_t)stream;
+    const void* v = pre + 2 * dh;
+#define ARGS q, ldq, k, ldk, v, ldqkv, o, ldo, dout, lddo, lse, delta, g, lddqkv, g + dh, lddqkv, g + 2 * dh, lddqkv, B, H, L, scale, st, &rbq, &rbk
+    return q_prescaled ? launch_bwd<bf16_t, 64, OD_BWD_NK, OD_BWD_NQ, true>(ARGS) : launch_bwd<bf16_t, 64, OD_BWD_NK, OD_BWD_NQ, false>(ARGS);
+#undef ARGS
 }

@@ -256,11 +256,27 @@ class DenoiserEngine:
         ops.uhead_fwd(xt, self._uhead_w(), fsum, self.U)
         ops.uhead_tail(fsum, self.ws.t["umod"], self.P("u_out.weight"), self.P("u_out.bias"), u, L, self.model.u_scale)
 
-    def attn_bwd_launch(self, qk, qkv, y, dy, lse, delta, dqk, dqkv):
-        """The attention backward of one layer exactly as `backward` launches it (also what bench.py times alone)."""
-        dh = self.dh
+    def fused_rope_bwd(self) -> bool:
+        """bf16 / head_dim 64: the backward of the q / k RMSNorm + RoPE runs in the attention backward's epilogues
+        (od_flash_attn_bwd_qkrope): dq, dk never exist in memory and the od_qk_norm_rope_bwd pass (3.2 GB per layer) is gone."""
+        return self.dtype == torch.bfloat16 and self.hd == 64
+
+    def attn_bwd_launch(self, i: int, dy: torch.Tensor, delta: torch.Tensor, dqkv: torch.Tensor):
+        """The backward of layer i's attention core + q / k norm + RoPE exactly as `backward` launches it (also what bench.py times
+        alone): dy = gradient of the attention output, dqkv <- gradient of the qkv projection; norm weight gradients accumulate."""
+        t, dh, p = self.ws.t, self.dh, f"net.layers.{i}."
+        qk, qkv, y, lse = t[f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
+        wq, wk = self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight")
+        gq, gk = self.G(p + "attn.q_norm.weight"), self.G(p + "attn.k_norm.weight")
+        scale = 1.0 / math.sqrt(self.hd)
+        if self.fused_rope_bwd():
+            ops.flash_attn_bwd_qkrope(qk[:, :dh], qk[:, dh:], qkv, y, dy, lse, delta, dqkv, wq, wk, t["rope"], gq, gk,
+                                      self.B, self.H, self.L, self.hd, scale, FP32_EPS, q_scale=self.q_scale, q_prescaled=True)
+            return
+        dqk = self.buf("d.qk", (self.M, 2 * dh))
         ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
-                           dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, 1.0 / math.sqrt(self.hd), q_prescaled=True)
+                           dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, scale, q_prescaled=True)
+        ops.qk_norm_rope_bwd(qkv, wq, wk, t["rope"], dqk, dqkv, gq, gk, self.B, self.L, self.H, self.hd, FP32_EPS, q_scale=self.q_scale)
 
     # ---- nn.Dropout1d(p) of the SwiGLU hidden state: a (B, Hp) factor per layer, 0 or 1 / (1 - p), drawn by torch's generator
     #      (as the reference's mask is) when the module is in training mode; `hh` is stored masked, so proj_o's weight gradient
@@ -302,7 +318,6 @@ class DenoiserEngine:
         dhh = self.buf("d.hh", (M, Hp))
         dvg = self.buf("d.vg", (M, 2 * Hp))
         dy = self.buf("d.y", (M, dh))
-        dqk = self.buf("d.qk", (M, 2 * dh))
         dqkv = self.buf("d.qkv", (M, 3 * dh))
         da = self.buf("d.a", (self.Ma, A))
         delta = self.buf("d.delta", (B, self.H, L), f32)
@@ -350,11 +365,7 @@ class DenoiserEngine:
             ops.rmsnorm_gate_residual_bwd(t[f"ao.{i}"], t[f"inv2.{i}"], ssg1, dx, dbr, dssg1, B, L)
             ops.gemm_tn(dbr, t[f"y.{i}"], self.G(p + "attn.out_proj.weight"), dbias=self.G(p + "attn.out_proj.bias"))
             ops.gemm_nt(dbr, self.W(p + "attn.out_proj", T=True), None, dy)
-            qk, qkv = t[f"qk.{i}"], t[f"qkv.{i}"]
-            self.attn_bwd_launch(qk, qkv, t[f"y.{i}"], dy, t[f"lse.{i}"], delta, dqk, dqkv)
-            ops.qk_norm_rope_bwd(qkv, self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, dqk, dqkv,
-                                 self.G(p + "attn.q_norm.weight"), self.G(p + "attn.k_norm.weight"), B, L, self.H,
-                                 self.hd, FP32_EPS, q_scale=self.q_scale)
+            self.attn_bwd_launch(i, dy, delta, dqkv)
             ops.gemm_tn(dqkv, t[f"h1.{i}"], self.G(p + "attn.qkv_proj.weight"), dbias=self.G(p + "attn.qkv_proj.bias"))
             ops.gemm_nt(dqkv, self.W(p + "attn.qkv_proj", T=True), None, dtmp)      # d h1 (== d cl)
             ops.gemm_tn(dtmp, a, self.G(p + "proj_cl.weight"), dbias=self.G(p + "proj_cl.bias"))

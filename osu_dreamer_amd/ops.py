@@ -223,6 +223,15 @@ def flash_attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, L, hd, scale, q
                                  B, H, L, hd, scale, int(q_prescaled), _stream(q))
 
 
+def flash_attn_bwd_qkrope(q, k, qkv, o, do, lse, delta, dqkv, wq, wk, table, dwq, dwk, B, H, L, hd, scale, eps, q_scale=1.0,
+                          q_prescaled=False):
+    """Attention backward with the backward of the q / k RMSNorm + RoPE in its epilogues (bf16, head_dim 64)."""
+    _f32(lse, delta, wq, wk, table, dwq, dwk)
+    _lib.lib().od_flash_attn_bwd_qkrope(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(qkv), _ld(qkv), _p(o), _ld(o), _p(do), _ld(do),
+                                        _p(lse), _p(delta), _p(dqkv), _ld(dqkv), _p(wq), _p(wk), _p(table), _p(dwq), _p(dwk),
+                                        B, H, L, hd, scale, eps, q_scale, int(q_prescaled), _stream(q))
+
+
 # ---------------------------------------------------------------- feed-forward
 def dwconv(x, w, bias, y, B, L, ksize):
     C = x.shape[1]

@@ -484,6 +484,56 @@ def test_flash_attention(dev, dtype, B, H, L, hd):
     assert rel_l2(dq2.float(), qs.grad / c) < tol
 
 
+@pytest.mark.parametrize("B,H,L", [(2, 2, 75), (1, 3, 200), (2, 1, 64), (1, 2, 321)])
+def test_flash_attn_bwd_qkrope_vs_autograd(dev, B, H, L):
+    """od_flash_attn_bwd_qkrope (bf16, head_dim 64): attention backward with the backward of the q / k RMSNorm + RoPE in the dQ / dK
+    kernels' epilogues, against torch autograd through the oracle's norm -> rope -> softmax attention on the same pre-norm projection,
+    and against the two separate entry points it replaces (od_flash_attn_bwd + od_qk_norm_rope_bwd).  Ragged lengths included."""
+    hd, dtype = 64, torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    M, dh = B * L, H * hd
+    scale = 1 / math.sqrt(hd)
+    q_scale = scale * math.log2(math.e)
+    qkv = mk((M, 3 * dh), g, dev, dtype)
+    wq, wk = 1 + .2 * mk((hd,), g, dev), 1 + .2 * mk((hd,), g, dev)
+    table = torch.zeros(L, hd // 2, 2, device=dev)
+    ops.rope_table(table, L, hd)
+    eps = torch.finfo(torch.float32).eps
+    qk = torch.zeros(M, 2 * dh, dtype=dtype, device=dev)
+    ops.qk_norm_rope(qkv, wq, wk, table, qk, B, L, H, hd, eps, q_scale=q_scale)
+    o = torch.zeros(M, dh, dtype=dtype, device=dev)
+    lse, delta = torch.zeros(B, H, L, device=dev), torch.zeros(B, H, L, device=dev)
+    ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], o, lse, B, H, L, hd, scale, q_prescaled=True)
+    do = mk((M, dh), g, dev, dtype)
+    # fused
+    dqkv = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
+    dwq, dwk = torch.zeros(hd, device=dev), torch.zeros(hd, device=dev)
+    ops.flash_attn_bwd_qkrope(qk[:, :dh], qk[:, dh:], qkv, o, do, lse, delta, dqkv, wq, wk, table, dwq, dwk, B, H, L, hd, scale, eps,
+                              q_scale=q_scale, q_prescaled=True)
+    # the two calls it replaces
+    dqk2, dqkv2 = torch.zeros_like(qk), torch.zeros_like(dqkv)
+    dwq2, dwk2 = torch.zeros(hd, device=dev), torch.zeros(hd, device=dev)
+    ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], o, do, lse, delta, dqk2[:, :dh], dqk2[:, dh:], dqkv2[:, 2 * dh:],
+                       B, H, L, hd, scale, q_prescaled=True)
+    ops.qk_norm_rope_bwd(qkv, wq, wk, table, dqk2, dqkv2, dwq2, dwk2, B, L, H, hd, eps, q_scale=q_scale)
+    assert torch.equal(dqkv[:, 2 * dh:], dqkv2[:, 2 * dh:])                       # dV: the same kernel code
+    assert rel_l2(dqkv.float(), dqkv2.float()) < 1e-2 and rel_l2(dwq, dwq2) < 1e-2 and rel_l2(dwk, dwk2) < 1e-2
+    # autograd reference (fp32, from the same bf16 pre-norm projection)
+    xr, wqr, wkr = leaf(qkv), leaf(wq), leaf(wk)
+    t = xr.reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    qn, kn = O.rope_half_split(O.head_rms_norm(t[0], wqr)), O.rope_half_split(O.head_rms_norm(t[1], wkr))
+    ref = (torch.softmax(qn @ kn.transpose(-1, -2) * scale, -1) @ t[2]).permute(0, 2, 1, 3).reshape(M, dh)
+    ref.backward(do.float().cpu())
+    tol = 1.5 * TOL[dtype]
+    for c0, c1 in ((0, dh), (dh, 2 * dh), (2 * dh, 3 * dh)):
+        assert rel_l2(dqkv.float()[:, c0:c1], xr.grad[:, c0:c1]) < tol, (c0, rel_l2(dqkv.float()[:, c0:c1], xr.grad[:, c0:c1]))
+    assert rel_l2(dwq, wqr.grad) < tol and rel_l2(dwk, wkr.grad) < tol
+    # not bf16 / head_dim 64: refused, the caller falls back to the two entry points
+    from osu_dreamer_amd._lib import HipKernelError
+    with pytest.raises(HipKernelError):
+        ops.flash_attn_bwd_qkrope(qk[:, :dh], qk[:, dh:], qkv, o, do, lse, delta, dqkv, wq, wk, table, dwq, dwk, B, 2 * H, L, 32, scale, eps)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ks", [3, 5])
 @pytest.mark.parametrize("L", [75, 21])          # long-run and short-run launch shapes (od_dwconv picks by size)
