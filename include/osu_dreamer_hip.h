@@ -139,6 +139,15 @@ int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* k, int ldk,
 int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                       int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk,
                       int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled, void* stream);
+/* Two-stream form of the above.  `aux` (od_attn_aux_create: one non-blocking side stream and two events, owned by the caller; NULL = exactly
+ * od_flash_attn_bwd) lets the dQ kernel run beside the dK/dV kernel — both depend on delta alone — so its workgroups fill the CUs the other
+ * kernel's last block round leaves idle (-1 % per layer at the bench shape).  Everything is ordered after `stream`'s earlier work and `stream`
+ * waits for the side stream before the call's results are used: the caller sees one stream.  Not capturable into a hipGraph while aux != NULL. */
+int od_attn_aux_create(void** aux_out);
+int od_attn_aux_destroy(void* aux);
+int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                          int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk,
+                          int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled, void* aux, void* stream);
 /* od_flash_attn_bwd and od_qk_norm_rope_bwd in one: q, k are the normed + rotated operands, qkv the PRE-norm projection [M, 3*H*hd]
  * (q | k | v column blocks; v is read from it), dqkv [M, 3*H*hd] receives the gradient of that projection (the backward of the norm + RoPE
  * runs on the dQ / dK accumulators in the attention kernels' epilogues: dq and dk never exist in memory), dwq / dwk [hd] += the norm weight

@@ -594,6 +594,9 @@ __device__ __forceinline__ void qk_rope_norm_bwd_row(const f32x4 (&a)[4], const 
 }
 // the wave's weight-gradient partials: sum over the 16 rows (lanes x) of each feature group g, 64 atomics per wave
 __device__ __forceinline__ void qk_rope_norm_bwd_dw(f32x4 (&dwacc)[4], float* dw, int x, int g) {
+#if defined(OD_RB_NO_DW)
+    return;      // timing experiment only: what the epilogue costs without its atomics
+#endif
 #pragma unroll
     for (int dt = 0; dt < 4; dt++)
 #pragma unroll
@@ -1133,6 +1136,15 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dq32_kernel(const bf16_t
 #ifndef OD_FWD32_NQB
 #define OD_FWD32_NQB 1    // 32-query blocks per wave
 #endif
+// host-side helper objects of the two-stream backward, created explicitly by the caller (od_attn_aux_create): the library itself holds no state
+struct AttnAux {
+#if !defined(OD_EMU)
+    hipStream_t side; hipEvent_t fork, join;
+#else
+    int unused;
+#endif
+};
+
 template <class T, int HD, bool PRE>
 int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* lse, int B,
                int H, int L, float scale, hipStream_t st) {
@@ -1155,7 +1167,7 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 template <class T, int HD, int NK, int NQ, bool PRE>
 int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout,
                int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H,
-               int L, float scale, hipStream_t st, const RopeBwdEpi* rbq = nullptr, const RopeBwdEpi* rbk = nullptr) {
+               int L, float scale, hipStream_t st, const RopeBwdEpi* rbq = nullptr, const RopeBwdEpi* rbk = nullptr, const AttnAux* aux = nullptr) {
     const long M = (long)B * L;
     constexpr bool CAN_RB = std::is_same<T, bf16_t>::value && HD == 64;
     const bool use_rb = CAN_RB && rbq && rbk;
@@ -1163,6 +1175,16 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     const RopeBwdEpi none{};
     OD_LAUNCH((attn_delta_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)o, ldo, (const T*)dout, lddo, delta,
               B, H, L, HD);
+    // Two-stream form: with a side stream (od_attn_aux_create) the dQ kernel runs beside the dK/dV kernel — both depend on delta alone — and its
+    // workgroups fill the CUs the other kernel's last block round leaves idle: 24.69 -> 24.43 ms per layer (profiles/r03h_ab_bwd_two_streams.txt).
+    hipStream_t st_q = st;
+#if !defined(OD_EMU)
+    static const int two_streams = od_env_int("OD_BWD_2STREAM", 1);      // 0: ignore the side stream (A/B)
+    if (aux && two_streams) {
+        if (hipEventRecord(aux->fork, st) != hipSuccess || hipStreamWaitEvent(aux->side, aux->fork, 0) != hipSuccess) return OD_ERR_ARG;
+        st_q = aux->side;
+    }
+#endif
 #ifndef OD_DKV_NW
 #define OD_DKV_NW 4      // waves per dK/dV workgroup (bf16): 8 = the Q/dO tiles streamed once per 256 keys
 #endif
@@ -1193,7 +1215,7 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     }
     constexpr int NWQ = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
     const int gq = attn_grid((L + 16 * NQ * NWQ - 1) / (16 * NQ * NWQ), B * H);
-#define DQ_ARGS dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
+#define DQ_ARGS dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st_q, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
               (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale
     if constexpr (CAN_RB) {
         if (use_rb) OD_LAUNCH_DYN_X((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE, true>), DQ_ARGS, *rbq);
@@ -1201,6 +1223,9 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     } else
         OD_LAUNCH_DYN_X((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), DQ_ARGS, none);
 #undef DQ_ARGS
+#if !defined(OD_EMU)
+    if (st_q != st) { if (hipEventRecord(aux->join, st_q) != hipSuccess || hipStreamWaitEvent(st, aux->join, 0) != hipSuccess) return OD_ERR_ARG; }
+#endif
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -1231,13 +1256,49 @@ extern "C" int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* 
 #endif
 extern "C" int od_flash_attn_bwd_passes(void) { return 7; }   // dK/dV kernel: S, dP, dV, dK; dQ kernel: S, dP, dQ
 
+extern "C" int od_attn_aux_create(void** aux_out) {
+    if (!aux_out) return OD_ERR_ARG;
+    AttnAux* a = new AttnAux();
+#if !defined(OD_EMU)
+    hipError_t e = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&a->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&a->join, hipEventDisableTiming);
+    if (e != hipSuccess) { delete a; return -(int)e - 1000; }
+#endif
+    *aux_out = a;
+    return 0;
+}
+extern "C" int od_attn_aux_destroy(void* aux) {
+    if (!aux) return OD_ERR_ARG;
+    AttnAux* a = (AttnAux*)aux;
+#if !defined(OD_EMU)
+    (void)hipStreamSynchronize(a->side);
+    (void)hipEventDestroy(a->fork); (void)hipEventDestroy(a->join); (void)hipStreamDestroy(a->side);
+#endif
+    delete a;
+    return 0;
+}
+
+extern "C" int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                                     int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq,
+                                     void* dk, int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled,
+                                     void* aux, void* stream);
+
 extern "C" int od_flash_attn_bwd(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                                  int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq,
                                  void* dk, int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled,
                                  void* stream) {
+    return od_flash_attn_bwd_aux(dtype, q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, hd, scale,
+                                 q_prescaled, nullptr, stream);
+}
+
+extern "C" int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
+                                     int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq,
+                                     void* dk, int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled,
+                                     void* aux, void* stream) {
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
-#define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st
+#define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st, nullptr, nullptr, (const AttnAux*)aux
 // Register tiles of the bf16 / hd 64 backward: 16-row tiles per wave.  Per streamed tile every wave pays a fixed budget — its LDS-DMA
 // pieces, the row-wise AND transposed fragment reads of the whole tile pair, the barrier — whatever it owns (removing the in-loop DMA takes
 // 25.5 -> 20.2 ms; deeper tile rings, trimmed loops and 8-wave workgroups change nothing or lose: profiles/r02l_ab_bwd_tile_budget.txt), so

@@ -77,6 +77,7 @@ class DenoiserEngine:
         # bumped whenever the workspace or the packed weights are re-allocated: anything that captured their addresses
         # (the sampler's hipGraph) is stale from then on
         self.generation = 0
+        self._attn_aux = None
 
     # ------------------------------------------------------------------ parameters
     def P(self, name: str) -> torch.Tensor:
@@ -257,9 +258,13 @@ class DenoiserEngine:
         ops.uhead_tail(fsum, self.ws.t["umod"], self.P("u_out.weight"), self.P("u_out.bias"), u, L, self.model.u_scale)
 
     def fused_rope_bwd(self) -> bool:
-        """bf16 / head_dim 64: the backward of the q / k RMSNorm + RoPE runs in the attention backward's epilogues
-        (od_flash_attn_bwd_qkrope): dq, dk never exist in memory and the od_qk_norm_rope_bwd pass (3.2 GB per layer) is gone."""
-        return self.dtype == torch.bfloat16 and self.hd == 64
+        """Whether the backward of the q / k RMSNorm + RoPE runs in the attention backward's epilogues (od_flash_attn_bwd_qkrope: dq, dk never
+        exist in memory, the 3.2 GB od_qk_norm_rope_bwd pass is gone).  Built, parity-tested and MEASURED SLOWER at the bench shape
+        (profiles/r03f_ab_rope_fused.txt: 26.7-26.9 ms against 25.5 + 0.67 ms; step 373-374 against 370 ms on the same box): the epilogue's
+        row loads / stores cost 0.4 ms per layer where no other wave of the workgroup computes, and its weight-gradient atomics (9.8 M per layer
+        onto 128 addresses) another 0.7.  Off unless OD_FUSED_ROPE_BWD=1."""
+        import os
+        return self.dtype == torch.bfloat16 and self.hd == 64 and os.environ.get("OD_FUSED_ROPE_BWD", "0") == "1"
 
     def attn_bwd_launch(self, i: int, dy: torch.Tensor, delta: torch.Tensor, dqkv: torch.Tensor):
         """The backward of layer i's attention core + q / k norm + RoPE exactly as `backward` launches it (also what bench.py times
@@ -274,8 +279,10 @@ class DenoiserEngine:
                                       self.B, self.H, self.L, self.hd, scale, FP32_EPS, q_scale=self.q_scale, q_prescaled=True)
             return
         dqk = self.buf("d.qk", (self.M, 2 * dh))
+        if self._attn_aux is None and qk.is_cuda:
+            self._attn_aux = ops.AttnAux()                  # side stream + events: the dQ kernel runs beside the dK/dV kernel
         ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
-                           dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, scale, q_prescaled=True)
+                           dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, scale, q_prescaled=True, aux=self._attn_aux)
         ops.qk_norm_rope_bwd(qkv, wq, wk, t["rope"], dqk, dqkv, gq, gk, self.B, self.L, self.H, self.hd, FP32_EPS, q_scale=self.q_scale)
 
     # ---- nn.Dropout1d(p) of the SwiGLU hidden state: a (B, Hp) factor per layer, 0 or 1 / (1 - p), drawn by torch's generator

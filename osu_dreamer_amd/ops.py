@@ -216,11 +216,31 @@ def flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale, x3=False, q_prescaled=Fa
                                  B, H, L, hd, scale, int(q_prescaled), _stream(q))
 
 
-def flash_attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, L, hd, scale, q_prescaled=False):
+class AttnAux:
+    """The side stream + events of the two-stream attention backward (od_attn_aux_create); owned by whoever plans the launches."""
+
+    def __init__(self):
+        import ctypes
+        self.handle = ctypes.c_void_p()
+        _lib.lib().od_attn_aux_create(ctypes.byref(self.handle))
+
+    def close(self):
+        if self.handle:
+            _lib.lib().od_attn_aux_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def flash_attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, L, hd, scale, q_prescaled=False, aux=None):
     _f32(lse, delta)
-    _lib.lib().od_flash_attn_bwd(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(do),
-                                 _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv),
-                                 B, H, L, hd, scale, int(q_prescaled), _stream(q))
+    _lib.lib().od_flash_attn_bwd_aux(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(do),
+                                     _ld(do), _p(lse), _p(delta), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv),
+                                     B, H, L, hd, scale, int(q_prescaled), aux.handle if aux is not None else None, _stream(q))
 
 
 def flash_attn_bwd_qkrope(q, k, qkv, o, do, lse, delta, dqkv, wq, wk, table, dwq, dwk, B, H, L, hd, scale, eps, q_scale=1.0,
