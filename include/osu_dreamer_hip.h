@@ -28,7 +28,12 @@ enum { OD_F32 = 0, OD_BF16 = 1,
        /* fp32 tensors, products as 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~4e-6 relative
         * error per GEMM instead of 4e-7, 1.7x the fp32 rate.  Accepted by od_gemm_nt and od_flash_attn_fwd
         * only (the no-grad forward / sampler); every other entry point takes OD_F32 for such tensors. */
-       OD_F32X3 = 2 };
+       OD_F32X3 = 2,
+       /* OD_F32X3 with the WEIGHT operand pre-split: W was written by od_pack_weight(OD_F32X3W, ...) as, per row and per 32-element K slab,
+        * 32 bf16 high halves followed by 32 bf16 low halves (same bytes and leading dimension as the fp32 matrix; K % 32 == 0).  The weights
+        * of a sampler call are constant over its 51 evaluations: splitting them once takes half of the split work out of every GEMM.
+        * Accepted by od_gemm_nt / od_gemm_nt_qkrope and od_pack_weight. */
+       OD_F32X3W = 3 };
 enum { OD_EPI_NONE = 0, OD_EPI_SILU = 1 };
 enum { OD_ACT_NONE = 0, OD_ACT_SILU = 1 };
 enum { OD_ERR_ARG = -1, OD_ERR_ALIGN = -2, OD_ERR_UNSUPPORTED = -3, OD_ERR_COMM = -4 };

@@ -52,6 +52,20 @@ __device__ __forceinline__ void frag_from_lds<f32x3_t>(od_frag<f32x3_t>& f, cons
     frag_from_lds_f32(f, tile, row, slab, g);
 }
 
+template <>
+__device__ __forceinline__ void frag_from_lds<f32x3w_t>(od_frag<f32x3w_t>& f, const unsigned char* tile, int row, int slab, int g) {
+    frag_from_lds_f32(f, tile, row, slab, g);
+}
+// the WEIGHT operand's fragment.  f32x3w_t: the staged row holds 32 bf16 high halves (16-byte slots 0..3) and 32 low halves (slots 4..7)
+// of the slab, written once by od_pack_weight — no conversion here.
+template <class T>
+__device__ __forceinline__ void frag_w_from_lds(od_frag<T>& f, const unsigned char* tile, int row, int slab, int g) { frag_from_lds<T>(f, tile, row, slab, g); }
+template <>
+__device__ __forceinline__ void frag_w_from_lds<f32x3w_t>(od_frag<f32x3w_t>& f, const unsigned char* tile, int row, int, int g) {
+    f.hi = *(const s16x8*)(tile + swz(row, g));
+    f.lo = *(const s16x8*)(tile + swz(row, 4 + g));
+}
+
 // One 128-byte-deep slab of MFMAs from a staged (A,B) pair.
 template <class T, int WMT>
 __device__ __forceinline__ void compute_stage(const unsigned char* sA, const unsigned char* sB, int wm, int wn, int lane,
@@ -64,7 +78,7 @@ __device__ __forceinline__ void compute_stage(const unsigned char* sA, const uns
 #pragma unroll
         for (int i = 0; i < WMT; i++) frag_from_lds<T>(fa[i], sA, wm * 16 * WMT + i * 16 + r16, s, g);
 #pragma unroll
-        for (int j = 0; j < 4; j++) frag_from_lds<T>(fb[j], sB, wn * 64 + j * 16 + r16, s, g);
+        for (int j = 0; j < 4; j++) frag_w_from_lds<T>(fb[j], sB, wn * 64 + j * 16 + r16, s, g);
 #pragma unroll
         for (int i = 0; i < WMT; i++)
 #pragma unroll
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict
         for (int sl = 0; sl < SLABS; sl++) {
             od_frag<T> fw[4], fa[8];
 #pragma unroll
-            for (int i = 0; i < 4; i++) frag_from_lds<T>(fw[i], sW, wrow(i), sl, g);
+            for (int i = 0; i < 4; i++) frag_w_from_lds<T>(fw[i], sW, wrow(i), sl, g);
 #pragma unroll
             for (int j = 0; j < 8; j++) frag_from_lds<T>(fa[j], sA, wm * 128 + j * 16 + x, sl, g);
 #pragma unroll
@@ -920,6 +934,10 @@ extern "C" int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int 
         return launch_nt<float>((const float*)A, lda, (const float*)W, ldw, bias, (float*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
     if (dtype == OD_F32X3)
         return launch_nt<f32x3_t>((const f32x3_t*)A, lda, (const f32x3_t*)W, ldw, bias, (f32x3_t*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
+    if (dtype == OD_F32X3W) {
+        if (K % 32) return OD_ERR_ALIGN;
+        return launch_nt<f32x3w_t>((const f32x3w_t*)A, lda, (const f32x3w_t*)W, ldw, bias, (f32x3w_t*)C, ldc, M, N, K, epilogue, accumulate, (hipStream_t)stream);
+    }
     return OD_ERR_ARG;
 }
 
@@ -938,6 +956,10 @@ extern "C" int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* 
         return launch_nt<float>((const float*)A, lda, (const float*)W, ldw, bias, (float*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
     if (dtype == OD_F32X3)
         return launch_nt<f32x3_t>((const f32x3_t*)A, lda, (const f32x3_t*)W, ldw, bias, (f32x3_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
+    if (dtype == OD_F32X3W) {
+        if (K % 32) return OD_ERR_ALIGN;
+        return launch_nt<f32x3w_t>((const f32x3w_t*)A, lda, (const f32x3w_t*)W, ldw, bias, (f32x3w_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
+    }
     return OD_ERR_ARG;
 }
 
@@ -956,7 +978,7 @@ extern "C" int od_gemm_nt_qkrope_split(int dtype, const void* A, int lda, const 
         return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
     }
     if (int rc = od_gemm_nt(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, OD_EPI_NONE, 0, stream)) return rc;
-    return od_qk_norm_rope(dtype == OD_F32X3 ? OD_F32 : dtype, C, ldc, wq, wk, table, qk_out, ldqk, M / L, L, H, hd, eps, q_scale, stream);
+    return od_qk_norm_rope((dtype == OD_F32X3 || dtype == OD_F32X3W) ? OD_F32 : dtype, C, ldc, wq, wk, table, qk_out, ldqk, M / L, L, H, hd, eps, q_scale, stream);
 }
 
 extern "C" int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M,

@@ -372,6 +372,22 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     od_t<T>::st(dst + i, v);
 }
 
+// fp32 master -> (hi, lo) bf16 halves, interleaved per 32-element K slab: dst[n][32 s + j] as storage holds, for slab s of row n, the 32 high
+// halves in its first 64 bytes and the 32 low halves in the next 64 (what frag_w_from_lds<f32x3w_t> in gemm.hip reads)
+__global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __restrict__ src, int N, int K, bf16_t* __restrict__ dst,
+                                                                int Np, int Kp, const int* __restrict__ row_map) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Np * Kp) return;
+    const int n = (int)(i / Kp), k = (int)(i % Kp);
+    const int sn = row_map ? row_map[n] : (n < N ? n : -1);
+    const float v = (sn >= 0 && k < K) ? src[(size_t)sn * K + k] : 0.f;
+    const bf16_t hi = od_f2bf(v);
+    const bf16_t lo = od_f2bf(v - od_bf2f(hi));
+    bf16_t* slab = dst + ((size_t)n * Kp + (k & ~31)) * 2;      // 32 floats = 64 bf16 slots
+    slab[k & 31] = hi;
+    slab[32 + (k & 31)] = lo;
+}
+
 }  // namespace
 
 #define DISPATCH_T(DT, CALL)                                       \
@@ -512,6 +528,12 @@ extern "C" int od_linear_small_bwd(const float* x, const float* W, const float* 
 extern "C" int od_pack_weight(int dtype, const float* src, int N, int K, void* dst, int Np, int Kp, int transpose,
                               const int* row_map, void* stream) {
     const long n = (long)Np * Kp;
+    if (dtype == OD_F32X3W) {
+        if (transpose || Kp % 32) return OD_ERR_UNSUPPORTED;
+        OD_LAUNCH(pack_weight_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, K, (bf16_t*)dst, Np, Kp, row_map);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     DISPATCH_T(dtype, OD_LAUNCH((pack_weight_kernel<T_>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, N, K, (T_*)dst, Np, Kp, transpose, row_map));
     OD_CHECK_LAUNCH();
     return 0;

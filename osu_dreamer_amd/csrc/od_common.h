@@ -63,12 +63,16 @@ __device__ __forceinline__ float od_exp2(float x) { return __builtin_amdgcn_exp2
 
 // compute-type tag: fp32 storage whose MFMA products run as 3 bf16 MFMAs (OD_F32X3, inference only)
 struct f32x3_t { float x; };
+// same, for GEMMs whose WEIGHT operand was split into (hi, lo) bf16 halves once at pack time (od_pack_weight with OD_F32X3W): the
+// activations are still split per fragment load, the weight fragments come out of LDS ready-made.  Pointers convert to f32x3_t*.
+struct f32x3w_t : f32x3_t {};
 
 template <class T> struct od_t;
 template <> struct od_t<f32x3_t> {
     static __device__ __forceinline__ float ld(const f32x3_t* p) { return p->x; }
     static __device__ __forceinline__ void st(f32x3_t* p, float v) { p->x = v; }
 };
+template <> struct od_t<f32x3w_t> : od_t<f32x3_t> {};
 template <> struct od_t<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
@@ -83,6 +87,7 @@ template <class T> __device__ __forceinline__ float od_round_to(float x);
 template <> __device__ __forceinline__ float od_round_to<float>(float x) { return x; }
 template <> __device__ __forceinline__ float od_round_to<bf16_t>(float x) { return od_bf2f(od_f2bf(x)); }
 template <> __device__ __forceinline__ float od_round_to<f32x3_t>(float x) { return x; }
+template <> __device__ __forceinline__ float od_round_to<f32x3w_t>(float x) { return x; }
 
 // 8 consecutive elements <-> 8 floats (p must be 16-byte aligned for bf16, 32 for f32)
 __device__ __forceinline__ void od_ld8(const float* p, float (&v)[8]) {
@@ -155,6 +160,7 @@ template <> struct od_frag<float> { float v[8]; };
 // f32x3: fp32 in memory, three bf16 MFMAs per product.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
 // (|x - hi - lo| <= 2^-17 |x|);  a.b ~ ahi.bhi + ahi.blo + alo.bhi, accumulated in fp32.
 template <> struct od_frag<f32x3_t> { s16x8 hi, lo; };
+template <> struct od_frag<f32x3w_t> : od_frag<f32x3_t> {};
 __device__ __forceinline__ void od_frag_pack(od_frag<float>& f, const float (&x)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) f.v[j] = x[j];

@@ -93,10 +93,14 @@ class DenoiserEngine:
             names += [p + "proj_cl", p + "attn.qkv_proj", p + "attn.out_proj", p + "ffn.proj_vg.1", p + "ffn.proj_o"]
         return names
 
-    def pack_weights(self, dtype: torch.dtype, train: bool):
-        """fp32 masters -> compute-dtype GEMM operands (and their transposes for backward-data)."""
+    def pack_weights(self, dtype: torch.dtype, train: bool, x3: bool = False):
+        """fp32 masters -> compute-dtype GEMM operands (and their transposes for backward-data).  `x3` (fp32 tensors, three bf16
+        MFMAs per product; no-grad only): the weights are split into their bf16 (hi, lo) halves HERE, once per call, instead of in every
+        fragment load of every GEMM of the 51 evaluations (ops.SplitWeight, OD_F32X3W) — wherever K is a multiple of 32."""
         dev = self.model.arena.data.device
-        key = (dtype, train, dev)
+        import os
+        x3 = bool(x3 and dtype == torch.float32 and not train and os.environ.get("OD_X3_SPLIT", "1") != "0")      # (env: A/B only)
+        key = (dtype, train, dev, x3)
         if self._packed_key != key:
             self._packed = {}
             self._packed_key = key
@@ -118,6 +122,8 @@ class DenoiserEngine:
                 Kp = self.Hp
             if n not in pk:
                 pk[n] = torch.empty(Np, Kp, dtype=dtype, device=dev)
+                if x3 and Kp % 32 == 0:
+                    pk[n] = ops.SplitWeight(pk[n])
                 if train:
                     pk[n + ".T"] = torch.empty(Kp, Np, dtype=dtype, device=dev)
                 if rmap is not None:

@@ -259,7 +259,7 @@ class DiffusionModel(nn.Module):
         audio, style, xt = self._f32c(audio), self._f32c(style), self._f32c(xt)
         B, _, L = xt.shape
         eng, dt = self.engine, self._dtype()
-        eng.pack_weights(dt, train=False)
+        eng.pack_weights(dt, train=False, x3=self._x3())
         eng.plan(B, L, audio.shape[0], dt, train=False, x3=self._x3())
         eng.conditioning(audio, style)
         u = torch.empty(B, dtype=torch.float32, device=xt.device)
@@ -277,7 +277,7 @@ class DiffusionModel(nn.Module):
         B, L, dev = style.shape[0], audio.shape[-1], audio.device
         x = torch.randn(B, self.emb_dim, L, device=dev) if x_init is None else self._f32c(x_init).clone()
         eng, dt = self.engine, self._dtype()
-        eng.pack_weights(dt, train=False)
+        eng.pack_weights(dt, train=False, x3=self._x3())
         eng.plan(B, L, audio.shape[0], dt, train=False, x3=self._x3())
         eng.conditioning(audio, style)                   # loop invariants, once
         u = eng.buf("smp.u", (B,), torch.float32)

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import OD_ACT_NONE, OD_ACT_SILU, OD_BF16, OD_EPI_NONE, OD_EPI_SILU, OD_F32, OD_F32X3
+from ._lib import OD_ACT_NONE, OD_ACT_SILU, OD_BF16, OD_EPI_NONE, OD_EPI_SILU, OD_F32, OD_F32X3, OD_F32X3W
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -22,9 +22,26 @@ def dt_code(dtype: torch.dtype) -> int:
     raise TypeError(f"unsupported compute dtype {dtype}")
 
 
-def mm_code(dtype: torch.dtype, x3: bool) -> int:
-    """MFMA compute type of the forward-only kernels: fp32 tensors may ask for the 3 x bf16 product."""
+class SplitWeight:
+    """A GEMM weight packed by `pack_weight(..., split=True)`: fp32-sized storage holding, per row and per 32-element K slab, the 32 bf16
+    high halves then the 32 low halves (OD_F32X3W).  Only the fp32-as-3-x-bf16 GEMMs read it."""
+
+    def __init__(self, storage: torch.Tensor):
+        self.t = storage
+
+
+def mm_code(dtype: torch.dtype, x3: bool, w=None) -> int:
+    """Compute-type code of a matrix product: fp32 tensors run as three bf16 MFMAs per product when `x3` (OD_F32X3; OD_F32X3W when
+    the weight was pre-split at pack time)."""
+    if isinstance(w, SplitWeight):
+        if not (x3 and dtype == torch.float32):
+            raise ValueError("a pre-split weight can only feed the fp32-as-3-x-bf16 product")
+        return OD_F32X3W
     return OD_F32X3 if (x3 and dtype == torch.float32) else dt_code(dtype)
+
+
+def _w(W):
+    return W.t if isinstance(W, SplitWeight) else W
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -47,22 +64,24 @@ def _f32(*ts):
 
 # ---------------------------------------------------------------- GEMMs
 def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False, x3=False):
+    code, W = mm_code(A.dtype, x3, W), _w(W)
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and tuple(C.shape) == (M, N)
     assert A.dtype == W.dtype == C.dtype
     _f32(bias)
-    _lib.lib().od_gemm_nt(mm_code(A.dtype, x3), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
+    _lib.lib().od_gemm_nt(code, _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
                           epilogue, int(accumulate), _stream(A))
 
 
 def gemm_nt_qkrope(A, W, bias, C, wq, wk, table, L, H, hd, eps, x3=False, q_scale=1.0):
     """qkv projection with q/k RMSNorm + RoPE in the epilogue (forward-only): C[:, :2*H*hd] normed + rotated."""
+    code, W = mm_code(A.dtype, x3, W), _w(W)
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and tuple(C.shape) == (M, N) and A.dtype == W.dtype == C.dtype
     _f32(bias, wq, wk, table)
-    _lib.lib().od_gemm_nt_qkrope(mm_code(A.dtype, x3), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
+    _lib.lib().od_gemm_nt_qkrope(code, _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
                                  _p(wq), _p(wk), _p(table), L, H, hd, eps, q_scale, _stream(A))
 
 
@@ -96,16 +115,19 @@ def colsum(G, out, n_cols=None):
 
 
 def pack_weight(src, dst, transpose=False, row_map=None):
-    """dst (compute dtype, zero padded) from the fp32 master `src` viewed as [N, K]."""
+    """dst (compute dtype, zero padded) from the fp32 master `src` viewed as [N, K].  A `SplitWeight` destination receives the
+    pre-split (hi, lo) bf16 layout of OD_F32X3W (K padded to a multiple of 32, no transpose)."""
     N = src.shape[0]
     K = src.numel() // N
     _f32(src)
+    code = OD_F32X3W if isinstance(dst, SplitWeight) else dt_code(_w(dst).dtype)
+    dst = _w(dst)
     if transpose:
         Kp, Np = dst.shape
     else:
         Np, Kp = dst.shape
     assert dst.is_contiguous()
-    _lib.lib().od_pack_weight(dt_code(dst.dtype), _p(src), N, K, _p(dst), Np, Kp, int(transpose), _p(row_map), _stream(src))
+    _lib.lib().od_pack_weight(code, _p(src), N, K, _p(dst), Np, Kp, int(transpose), _p(row_map), _stream(src))
 
 
 # ---------------------------------------------------------------- per-sample linears (fp32)

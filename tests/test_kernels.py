@@ -102,6 +102,15 @@ def test_gemm_nt_f32x3(dev, M, N, K):
     assert not torch.equal(C, C32), "the x3 request must reach a different kernel"
     ops.gemm_nt(A, W, b, C, epilogue=ops.OD_EPI_SILU, x3=True)
     assert rel_l2(C, O.silu(ref)) < 2e-5
+    # OD_F32X3W: the weight split into its (hi, lo) bf16 halves once at pack time — the same three products, bit for bit
+    Ws = ops.SplitWeight(torch.zeros(N, K, device=dev))
+    ops.pack_weight(W, Ws)
+    Cs = torch.zeros(M, N, device=dev)
+    ops.gemm_nt(A, Ws, b, Cs, x3=True)
+    ops.gemm_nt(A, W, b, C, x3=True)
+    assert torch.equal(Cs, C)
+    with pytest.raises(ValueError):
+        ops.gemm_nt(A, Ws, b, Cs)                       # a split weight has no meaning for the plain fp32 product
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
