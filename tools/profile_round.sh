@@ -18,5 +18,9 @@ done
 rm -rf $out/kt $out/pmc/p1 $out/pmc/p2 $out/pmc/p3 $out/s_bf16 $out/s_f32 $out/s_x3
 # the 50-step sampler against the reference's own run (writes gpurun_out/sampler_parity.json, tagged with the library's source hash)
 timeout 600 python3 -m pytest tests/test_sampler50.py -m gpu -q > $out/sampler50_test.txt 2>&1; cp gpurun_out/sampler_parity.json $out/sampler_parity.json
+# the bench line quotes the counter / parity records of THIS build: put them where bench.py looks (copy the same files into the
+# repository's profiles/ afterwards; a record whose kernel_src_sha differs from the library's is ignored by bench.py)
+round=${2:-r03}
+cp $out/traffic.json profiles/${round}_traffic.json; cp $out/sampler_parity.json profiles/${round}_sampler_parity.json
 timeout 900 python3 bench.py > $out/bench.json 2> $out/bench.err
 tail -c 600 $out/bench.json
