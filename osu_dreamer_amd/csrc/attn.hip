@@ -808,6 +808,12 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
     }
 }
 
+// (Round 3 also built a software-pipelined form of the dK/dV loop — the score / softmax half "P1" of one 32-query half-tile interleaved with the
+// MFMA-only dV / dK half "P2" of the PREVIOUS half-tile, a ring of three LDS stages, buffer-addressed asm DMA, lane-constant LDS offsets, the
+// MFMA / filler interleave pinned with sched_group_barrier — so that every stretch of the loop carries the same ~2 fillers per MFMA gap instead of 3
+// then 0.7.  With both halves' P / dS fragments live beside P1's and P2's temporaries it fits only 32 keys per wave (48: 416 B of scratch, 94 ms), and at
+// 32 keys it measured 27.0 ms (scheduler-placed) / 28.6 ms (pinned) per layer against 25.0 for this kernel: profiles/r03l_ab_dkv_pipe.txt, r03m.  Removed.)
+
 // dQ: block owns 4 waves x NQ*16 queries; loop over 64-key tiles.
 //   S^T = K Q^T ; dP^T = V dO^T ; dS^T = P^T*(dP^T - delta)*scale ; dQ^T += K^T dS^T
 template <class T, int HD, int NQ, int NW, bool PRE, bool RB = false>
