@@ -2,9 +2,12 @@
 inputs, in fp32 (tolerance 2e-5 rel-L2) and bf16 (2e-2).  Runs on the emulator build
 (CPU) and, marked gpu, on the MI355X through the real C ABI."""
 import math
+import os
 
 import pytest
 import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import denoiser_oracle as O
 from osu_dreamer_amd import ops
@@ -85,6 +88,28 @@ def test_gemm_nt_qkrope_equals_gemm_then_rope(dev, dtype, H, hd, L, B, K):
     if dtype == torch.float32:
         ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps, x3=True, q_scale=0.18)
         assert rel_l2(fused[:, :2 * dh], qk) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(512, 1024), (512, 1408), (3072, 512)])
+def test_gemm_nt_sampler_rows(N, K):
+    """od_gemm_nt at the sampler's M = 4 x 1115 = 4460 rows, bf16 and fp32-as-3-x-bf16 with a pre-split weight, against torch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    M = 4460
+    A32, W32, b = mk((M, K), g, dev), mk((N, K), g, dev, scale=0.1), mk((N,), g, dev)
+    ref = A32.double() @ W32.double().t() + b.double()
+    C = torch.zeros(M, N, device=dev)
+    Ws = ops.SplitWeight(torch.zeros(N, K, device=dev)); ops.pack_weight(W32, Ws)
+    ops.gemm_nt(A32, Ws, b, C, x3=True)
+    assert float((C.double() - ref).norm() / ref.norm()) < 2e-5
+    A16, W16 = A32.bfloat16(), W32.bfloat16()
+    C16 = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm_nt(A16, W16, b, C16)
+    ref16 = A16.double() @ W16.double().t() + b.double()
+    assert float((C16.double() - ref16).norm() / ref16.norm()) < 5e-3
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 136, 96), (300, 384, 192), (512, 512, 256)])
