@@ -289,22 +289,44 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x
     }
 }
 
-// ------------------------------------------------------------ per-sample linear: one wave per output feature
+// ------------------------------------------------------------ per-sample linears (ssg1 / ssg2 / u_mod / proj_style: B <= a few dozen rows)
+// Round 3: these were one wave per output feature walking the batch serially (a dependent load -> 6-shuffle reduction chain per sample:
+// 72 us for the 32 x 512 -> 1536 ssg linear, 84 + 27 us for its backward; 3.3 ms of every training step and 1.2 ms of every sampler call).
+// Now: forward = a 32 (samples) x 8 (features) output tile per block, both operands staged through LDS in 256-deep K chunks, one thread
+// per output (no cross-lane reduction, W read once); dW = one thread per weight element, the batch in registers (dpre[b][n] is block-uniform:
+// scalar loads); dx = 32 x 256 output tiles over 32-row slices of N (W read once, coalesced), fp32 atomics into dx.
+constexpr int LS_KC = 256, LS_NB = 8;
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            float* __restrict__ pre, int B, int N, int K, int act) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    for (int b = 0; b < B; b++) {
-        float s = 0.f;
-        for (int k = lane; k < K; k += 64) s += x[(size_t)b * K + k] * W[(size_t)n * K + k];
-        s = od_wave_sum(s);
-        if (lane == 0) {
-            s += bias ? bias[n] : 0.f;
-            if (pre) pre[(size_t)b * N + n] = s;
-            out[(size_t)b * N + n] = act == OD_ACT_SILU ? od_silu(s) : s;
+    __shared__ __attribute__((aligned(16))) float xs[32][LS_KC + 4];
+    __shared__ __attribute__((aligned(16))) float ws[LS_NB][LS_KC + 4];
+    const int b0 = blockIdx.y * 32, n0 = blockIdx.x * LS_NB;
+    const int bl = threadIdx.x & 31, nl = threadIdx.x >> 5;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += LS_KC) {
+        const int kc = K - k0 < LS_KC ? K - k0 : LS_KC;
+        for (int i = threadIdx.x; i < 32 * LS_KC; i += 256) {
+            const int r = i / LS_KC, c = i % LS_KC;
+            xs[r][c] = (b0 + r < B && c < kc) ? x[(size_t)(b0 + r) * K + k0 + c] : 0.f;
         }
+        for (int i = threadIdx.x; i < LS_NB * LS_KC; i += 256) {
+            const int r = i / LS_KC, c = i % LS_KC;
+            ws[r][c] = (n0 + r < N && c < kc) ? W[(size_t)(n0 + r) * K + k0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int c = 0; c < LS_KC; c += 4) {
+            const f32x4 a = *(const f32x4*)&xs[bl][c], w = *(const f32x4*)&ws[nl][c];
+            acc += a[0] * w[0]; acc += a[1] * w[1]; acc += a[2] * w[2]; acc += a[3] * w[3];
+        }
+        __syncthreads();
+    }
+    const int b = b0 + bl, n = n0 + nl;
+    if (b < B && n < N) {
+        const float s = acc + (bias ? bias[n] : 0.f);
+        if (pre) pre[(size_t)b * N + n] = s;
+        out[(size_t)b * N + n] = act == OD_ACT_SILU ? od_silu(s) : s;
     }
 }
 __global__ __launch_bounds__(256) void linear_small_dpre_kernel(const float* __restrict__ pre, const float* __restrict__ dout,
@@ -313,49 +335,62 @@ __global__ __launch_bounds__(256) void linear_small_dpre_kernel(const float* __r
     if (i >= n) return;
     dpre[i] = act == OD_ACT_SILU ? dout[i] * od_silu_grad(pre[i]) : dout[i];
 }
-// dW[n][k] += sum_b dpre[b][n] x[b][k]; db[n] += sum_b dpre[b][n]     (wave per n, lanes over k)
+// dW[n][k] += sum_b dpre[b][n] x[b][k]; db[n] += sum_b dpre[b][n]     (block = 256 consecutive k of ONE n: dpre[b][n] is block-uniform)
 __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
                                                               float* __restrict__ dW, float* __restrict__ db, int B, int N, int K) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    if (dW)
-        for (int k = lane; k < K; k += 64) {
-            float s = 0.f;
-            for (int b = 0; b < B; b++) s += dpre[(size_t)b * N + n] * x[(size_t)b * K + k];
-            dW[(size_t)n * K + k] += s;
+    const int n = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (dW && k < K) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 3 < B; b += 4) {          // four independent loads in flight
+            s0 += dpre[(size_t)b * N + n] * x[(size_t)b * K + k];
+            s1 += dpre[(size_t)(b + 1) * N + n] * x[(size_t)(b + 1) * K + k];
+            s2 += dpre[(size_t)(b + 2) * N + n] * x[(size_t)(b + 2) * K + k];
+            s3 += dpre[(size_t)(b + 3) * N + n] * x[(size_t)(b + 3) * K + k];
         }
-    if (db && lane == 0) {
+        for (; b < B; b++) s0 += dpre[(size_t)b * N + n] * x[(size_t)b * K + k];
+        dW[(size_t)n * K + k] += (s0 + s1) + (s2 + s3);
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
         for (int b = 0; b < B; b++) s += dpre[(size_t)b * N + n];
         db[n] += s;
     }
 }
-// dx[b][k] (+)= sum_n dpre[b][n] W[n][k]   — block = 64 k-columns x 4 n-slices, LDS-reduced
+// dx[b][k] += sum_n dpre[b][n] W[n][k]: block = 32 samples x 256 columns over a 32-row slice of N, one thread per column with the 32
+// sample accumulators in registers; the dpre tile is staged transposed ([n][b]) so a thread reads four samples per (broadcast) LDS read;
+// the slices meet in dx through fp32 atomics (dx is zeroed by the launcher when it does not accumulate).
+constexpr int LS_NR = 32;
 __global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __restrict__ W, const float* __restrict__ dpre,
-                                                              float* __restrict__ dx, int accumulate, int B, int N, int K) {
-    __shared__ float red[4][64];
-    const int b = blockIdx.y;
-    const int kl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + kl;
-    float s = 0.f;
-    if (k < K) {
-        // 8 independent loads in flight per lane (the loop is latency-bound otherwise: N/4 dependent iterations)
-        float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int n = slice;
-        for (; n + 28 < N; n += 32) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) s8[j] += dpre[(size_t)b * N + n + 4 * j] * W[(size_t)(n + 4 * j) * K + k];
-        }
-        for (; n < N; n += 4) s8[0] += dpre[(size_t)b * N + n] * W[(size_t)n * K + k];
-        s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+                                                              float* __restrict__ dx, int B, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float ds[LS_NR][32];
+    const int n0 = blockIdx.x * LS_NR, b0 = blockIdx.y * 32, k = blockIdx.z * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < LS_NR * 32; i += 256) {
+        const int bl = i / LS_NR, nl = i % LS_NR;           // consecutive threads: consecutive n of one sample (coalesced)
+        ds[nl][bl] = (b0 + bl < B && n0 + nl < N) ? dpre[(size_t)(b0 + bl) * N + n0 + nl] : 0.f;
     }
-    red[slice][kl] = s;
     __syncthreads();
-    if (slice == 0 && k < K) {
-        s = red[0][kl] + red[1][kl] + red[2][kl] + red[3][kl];
-        if (accumulate) dx[(size_t)b * K + k] += s; else dx[(size_t)b * K + k] = s;
+    if (k >= K) return;
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc[i] = 0.f;
+    const int nr = N - n0 < LS_NR ? N - n0 : LS_NR;
+    for (int nl = 0; nl < nr; nl++) {
+        const float w = W[(size_t)(n0 + nl) * K + k];
+#pragma unroll
+        for (int q4 = 0; q4 < 8; q4++) {
+            const f32x4 d = *(const f32x4*)&ds[nl][4 * q4];
+            acc[4 * q4] += d[0] * w; acc[4 * q4 + 1] += d[1] * w; acc[4 * q4 + 2] += d[2] * w; acc[4 * q4 + 3] += d[3] * w;
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 32; i++)
+        if (b0 + i < B) atomicAdd(dx + (size_t)(b0 + i) * K + k, acc[i]);
+}
+
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
 }
 
 // ------------------------------------------------------------ fp32 master weight -> packed compute copy
@@ -507,7 +542,7 @@ extern "C" int od_dwconv_bwd(int dtype, const void* x, int ldx, const float* w, 
 
 extern "C" int od_linear_small(const float* x, const float* W, const float* b, float* out, float* pre, int B, int N, int K, int act,
                                void* stream) {
-    OD_LAUNCH(linear_small_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, b, out, pre, B, N, K, act);
+    OD_LAUNCH(linear_small_kernel, dim3((N + LS_NB - 1) / LS_NB, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, W, b, out, pre, B, N, K, act);
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -518,9 +553,13 @@ extern "C" int od_linear_small_bwd(const float* x, const float* W, const float* 
     const long n = (long)B * N;
     OD_LAUNCH(linear_small_dpre_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, dout, dpre, n, act);
     if (dW || db)
-        OD_LAUNCH(linear_small_dw_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (const float*)dpre, dW, db, B, N, K);
-    if (dx)
-        OD_LAUNCH(linear_small_dx_kernel, dim3((K + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, W, (const float*)dpre, dx, accumulate_dx, B, N, K);
+        OD_LAUNCH(linear_small_dw_kernel, dim3((K + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, x, (const float*)dpre, dW, db, B, N, K);
+    if (dx) {
+        if (!accumulate_dx)
+            OD_LAUNCH(zero_f32_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx, (long)B * K);
+        OD_LAUNCH(linear_small_dx_kernel, dim3((N + LS_NR - 1) / LS_NR, (B + 31) / 32, (K + 255) / 256), dim3(256), 0, (hipStream_t)stream, W,
+                  (const float*)dpre, dx, B, N, K);
+    }
     OD_CHECK_LAUNCH();
     return 0;
 }

@@ -18,6 +18,15 @@ for s in gemm rowops misc heads optim attn style latent comm; do
 done
 for p in $PIDS; do wait $p || { echo "emulator build failed" >&2; exit 1; }; done
 SHA=$(bash $CS/source_sha.sh)
-g++ -O1 -fPIC -DOD_SRC_SHA="\"$SHA\"" -c $CS/version.cpp -o build/version.o
-/opt/rocm/lib/llvm/bin/clang++ -shared -fPIC $OBJS build/version.o -o $OUT
+# relink only when something changed, and atomically (tmp + mv): parallel test workers may be loading the library meanwhile
+stale=0
+[ -f "$OUT" ] || stale=1
+for o in $OBJS; do [ "$o" -nt "$OUT" ] && stale=1; done
+[ -f build/sha.txt ] && [ "$(cat build/sha.txt)" = "$SHA" ] || stale=1
+if [ $stale = 1 ]; then
+  g++ -O1 -fPIC -DOD_SRC_SHA="\"$SHA\"" -c $CS/version.cpp -o build/version.o
+  /opt/rocm/lib/llvm/bin/clang++ -shared -fPIC $OBJS build/version.o -o $OUT.tmp.$$
+  mv -f $OUT.tmp.$$ $OUT
+  echo "$SHA" > build/sha.txt
+fi
 echo "built $OUT"

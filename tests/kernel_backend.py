@@ -15,8 +15,18 @@ EMU_DIR = os.path.join(REPO, "tests", "emu")
 EMU_SO = os.path.join(EMU_DIR, "libod_emu.so")
 
 
+_built = False
+
+
 def build_emu():
-    subprocess.check_call(["bash", os.path.join(EMU_DIR, "build_emu.sh")], stdout=subprocess.DEVNULL)
+    """Build (once per process, one process at a time: pytest-xdist workers share the tree) the emulator library."""
+    global _built
+    if not _built:
+        import fcntl
+        with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["bash", os.path.join(EMU_DIR, "build_emu.sh")], stdout=subprocess.DEVNULL)
+        _built = True
     return EMU_SO
 
 

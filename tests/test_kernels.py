@@ -323,9 +323,9 @@ def test_pack_weight(dev, dtype):
     assert torch.equal(d2.float().cpu(), ref2.to(dtype).float())
 
 
-def test_linear_small(dev):
+@pytest.mark.parametrize("B,N,K", [(3, 50, 40), (32, 96, 512), (35, 70, 300), (4, 33, 513)])     # one tile; the ssg shape (two K chunks); ragged B > 32 / N / K
+def test_linear_small(dev, B, N, K):
     g = torch.Generator().manual_seed(4)
-    B, N, K = 3, 50, 40
     x, W, b, dout = mk((B, K), g, dev), mk((N, K), g, dev, scale=.3), mk((N,), g, dev), mk((B, N), g, dev)
     for act in (ops.OD_ACT_NONE, ops.OD_ACT_SILU):
         out, pre = torch.zeros(B, N, device=dev), torch.zeros(B, N, device=dev)
@@ -339,6 +339,9 @@ def test_linear_small(dev):
         dW, db, dx, dpre = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev), torch.ones(B, K, device=dev), torch.zeros(B, N, device=dev)
         ops.linear_small_bwd(x, W, pre, dout, dpre, dW, db, dx, True, act)
         assert rel_l2(dW, Wr.grad) < 1e-5 and rel_l2(db, br.grad) < 1e-5 and rel_l2(dx - 1, xr.grad) < 1e-5
+        dx2 = torch.full((B, K), 7.0, device=dev)                 # not accumulating: whatever dx held is overwritten
+        ops.linear_small_bwd(x, W, pre, dout, dpre, None, None, dx2, False, act)
+        assert rel_l2(dx2, xr.grad) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
