@@ -911,7 +911,11 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
         }
     }
     const int tiles = ((N + BN - 1) / BN) * ((K + BM - 1) / BM);
-    int splits = (2048 + tiles - 1) / tiles;                 // aim for ~2048 workgroups (8 per CU)
+    // ~2048 workgroups (8 per CU) — but every M-split costs N x K fp32 atomics, and with few output tiles that is what the launch waits for
+    // (proj_cl's dW, 4 tiles: 512 splits = 33.5 M atomics ~ 0.1 ms of a 0.155 ms launch): large-M launches with <= 8 tiles aim for 512
+    static const int few_tile_wgs = od_env_int("OD_TN_SMALL_WGS", 512);
+    const int target_wgs = (tiles <= 8 && M >= OD_GEMM_BIG_MIN_M) ? few_tile_wgs : 2048;
+    int splits = (target_wgs + tiles - 1) / tiles;
     int mpb = (M + splits - 1) / splits;
     mpb = ((mpb + BR - 1) / BR) * BR;
     if (mpb < 4 * BR) mpb = 4 * BR;
