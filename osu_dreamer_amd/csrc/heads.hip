@@ -30,7 +30,6 @@ struct UHeadSmem {
     float z3s[MAXU][UW + 1];   // later reused for dz3
     float g4s[MAXU][UW + 1];   // dz4, later dz1
     float w4s[MAXU][MAXU + 1];
-    float w4t[MAXU][MAXU + 4];   // w4 transposed ([c'][c], rows 16-byte aligned): a thread's 8 output channels of one c' in two 16-byte reads
 };
 
 // forward pass of one window into LDS; returns nothing.  l0 = first owned frame.
@@ -65,30 +64,8 @@ __device__ __forceinline__ void uhead_window_fwd(UHeadSmem& S, const float* __re
 }
 
 __device__ __forceinline__ void uhead_load_w4(UHeadSmem& S, const UHeadW& P, int U) {
-    for (int idx = threadIdx.x; idx < U * U; idx += 256) { S.w4s[idx / U][idx % U] = P.w4[idx]; S.w4t[idx % U][idx / U] = P.w4[idx]; }
+    for (int idx = threadIdx.x; idx < U * U; idx += 256) S.w4s[idx / U][idx % U] = P.w4[idx];
     __syncthreads();
-}
-
-// z4[c][i] = b4[c] + sum_c' w4[c][c'] z3[c'][i] for the thread's channels c = grp * cpg + q (cpg = U / 8 <= 8) of frame i.  c' is the outer
-// loop: one z3 read and two 16-byte weight reads per c' feed all eight channels (the channel-outer form read LDS twice per FMA).
-__device__ __forceinline__ void uhead_z4(const UHeadSmem& S, const UHeadW& P, int U, int grp, int cpg, int i, float (&z)[MAXU / 8]) {
-#pragma unroll
-    for (int q = 0; q < MAXU / 8; q++) z[q] = q < cpg ? P.b4[grp * cpg + q] : 0.f;
-    if (cpg == 8) {
-        for (int cc = 0; cc < U; cc++) {
-            const float zz = S.z3s[cc][i];
-            const f32x4 w0 = *(const f32x4*)&S.w4t[cc][grp * 8], w1 = *(const f32x4*)&S.w4t[cc][grp * 8 + 4];
-            z[0] += w0[0] * zz; z[1] += w0[1] * zz; z[2] += w0[2] * zz; z[3] += w0[3] * zz;
-            z[4] += w1[0] * zz; z[5] += w1[1] * zz; z[6] += w1[2] * zz; z[7] += w1[3] * zz;
-        }
-    } else {
-        for (int cc = 0; cc < U; cc++) {
-            const float zz = S.z3s[cc][i];
-#pragma unroll
-            for (int q = 0; q < MAXU / 8; q++)
-                if (q < cpg) z[q] += S.w4t[cc][grp * cpg + q] * zz;
-        }
-    }
 }
 
 __global__ __launch_bounds__(256) void uhead_fwd_kernel(const float* __restrict__ xt, UHeadW P, float* __restrict__ fsum,
@@ -107,11 +84,15 @@ __global__ __launch_bounds__(256) void uhead_fwd_kernel(const float* __restrict_
         uhead_window_fwd(S, xt, P, b, l0, E, L, U);
         const int f = l0 - 1 + i;
         const bool own = (i >= 1 && i < UW - 1 && f < L);
-        float z4[MAXU / 8];
-        uhead_z4(S, P, U, grp, cpg, i, z4);
 #pragma unroll
-        for (int q = 0; q < MAXU / 8; q++)
-            if (q < cpg && own) acc[q] += od_silu(z4[q]);
+        for (int q = 0; q < MAXU / 8; q++) {
+            if (q < cpg) {
+                const int c = grp * cpg + q;
+                float z = P.b4[c];
+                for (int cc = 0; cc < U; cc++) z += S.w4s[c][cc] * S.z3s[cc][i];
+                if (own) acc[q] += od_silu(z);
+            }
+        }
         __syncthreads();
     }
 #pragma unroll
@@ -152,13 +133,12 @@ __global__ __launch_bounds__(256) void uhead_bwd_kernel(const float* __restrict_
         const bool inr = (f >= 0 && f < L);
         const bool own = (i >= 1 && i < UW - 1 && f < L);
         // dz4 for every ext-1 frame
-        float z4[MAXU / 8];
-        uhead_z4(S, P, U, grp, cpg, i, z4);
 #pragma unroll
         for (int q = 0; q < MAXU / 8; q++) {
             if (q < cpg) {
                 const int c = grp * cpg + q;
-                const float z = z4[q];
+                float z = P.b4[c];
+                for (int cc = 0; cc < U; cc++) z += S.w4s[c][cc] * S.z3s[cc][i];
                 const float g = inr ? dfm[(size_t)b * U + c] * invL * od_silu_grad(z) : 0.f;
                 S.g4s[c][i] = g;
                 const float s = red32(own ? g : 0.f);
@@ -186,12 +166,12 @@ __global__ __launch_bounds__(256) void uhead_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int q = 0; q < MAXU / 8; q++) {
             dz3v[q] = 0.f;
-        }
-        for (int c = 0; c < U; c++) {             // c-outer: one dz4 read per c feeds the thread's eight c' (the weight reads are wave-broadcast)
-            const float gg = S.g4s[c][i];
-#pragma unroll
-            for (int q = 0; q < MAXU / 8; q++)
-                if (q < cpg) dz3v[q] += S.w4s[c][grp * cpg + q] * gg;
+            if (q < cpg) {
+                const int cc = grp * cpg + q;
+                float s = 0.f;
+                for (int c = 0; c < U; c++) s += S.w4s[c][cc] * S.g4s[c][i];
+                dz3v[q] = s;
+            }
         }
         __syncthreads();
 #pragma unroll
