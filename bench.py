@@ -297,6 +297,27 @@ def ldm_bench(device):
     return {"workload": "LDM.sample: 72x30093 spectrogram (3 min), 4 difficulties, 50 steps, default widths", **out}
 
 
+def h2d_leg(batch, device, ms_step):
+    """What the boundary costs when the batch arrives in HOST memory (the feeder's pinned tensors, osu_dreamer_amd/data.py; `value` is
+    quoted with inputs resident in HBM): one batch copied host -> device on the launch stream, timed with HIP events, and the step
+    rate with that copy serialised in front of every step (Trainer.fit does exactly that; a prefetching feeder would hide it)."""
+    host = [t.detach().cpu().pin_memory() for t in batch]
+    for t in host:
+        t.to(device, non_blocking=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        for t in host:
+            t.to(device, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    nbytes = sum(t.numel() * t.element_size() for t in host)
+    return {"batch_mb": round(nbytes / 1e6, 1), "h2d_ms": round(ms, 3), "h2d_gb_per_s": round(nbytes / ms / 1e6, 1),
+            "steps_per_s_with_serial_h2d": round(1e3 / (ms_step + ms), 4)}
+
+
 def forward_target_shape(tr, device, B=64, L=8192):
     """north_star's target shape: denoiser FORWARD at batch 64 x 8192 frames, bf16.  Reports the binding
     (MFMA) fraction and, because the target was phrased against HBM, the HBM fraction of the algorithmic
@@ -447,6 +468,7 @@ def main():
                                   "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
         if not args.no_extras and world == 1:
             line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
+            line["pcie_inclusive"] = h2d_leg(batch, device, ms)
             line["forward_64x8192"] = forward_target_shape(tr, device)
             line["sampler"] = sampler_bench(device)
             line["ldm_sample"] = ldm_bench(device)

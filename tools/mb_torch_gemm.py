@@ -7,7 +7,8 @@ from osu_dreamer_amd import ops
 dev = torch.device("cuda:0")
 bf = torch.bfloat16
 for M in (262144, 4460):
-    for name, N, K in (("qkv", 3072, 512), ("out", 512, 1024), ("vg", 2816, 512), ("proj_o", 512, 1408), ("d_qkv", 512, 3072)):
+    for name, N, K in (("qkv", 3072, 512), ("out", 512, 1024), ("vg", 2816, 512), ("proj_o", 512, 1408), ("d_qkv", 512, 3072), ("d_vg", 512, 2816),
+                       ("d_out", 1024, 512), ("d_proj_o", 1408, 512)):
         A = torch.randn(M, K, device=dev).to(bf); W = torch.randn(N, K, device=dev).to(bf)
         C = torch.empty(M, N, dtype=bf, device=dev); bias = torch.zeros(N, device=dev)
         it = 5 if M > 100000 else 50
