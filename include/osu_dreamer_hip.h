@@ -50,6 +50,16 @@ const char* od_error_string(int code);
  *           model.py:45 (proj_audio), and their autograd backward-data. */
 int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                int M, int N, int K, int epilogue, int accumulate, void* stream);
+/* The same product through the vendor library (hipBLASLt), for PLAIN GEMMs only — no epilogue but the bias, no accumulate, bf16.  At
+ * M = 262,144 the library's hand-scheduled assembly kernel is 20-27 % faster than gemm_nt_big_kernel on the four long-K, N = 512 shapes of a
+ * layer (profiles/r03_gemm_vs_vendor.txt); the host routes exactly those there.  od_vendor_gemm_create binds the library at run time
+ * (dlopen(libpath), "libhipblaslt.so" when NULL / empty) and returns a handle object the caller owns; `workspace` is caller-owned device
+ * memory the library may use (its size is part of the plan: keep it constant).  Any failure — library missing, shape unsupported — is
+ * OD_ERR_UNSUPPORTED, and the caller uses od_gemm_nt.  Not for hipGraph capture (training path only). */
+int od_vendor_gemm_create(void** vg_out, const char* libpath);
+int od_vendor_gemm_destroy(void* vg);
+int od_gemm_nt_vendor(void* vg, int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
+                      int M, int N, int K, void* workspace, long workspace_bytes, void* stream);
 /* the qkv projection with the q/k RMSNorm + RoPE applied in its epilogue (no-grad forward / sampler: no separate
  * od_qk_norm_rope pass): C[:, :2*H*hd] = rope(rms_norm(A W^T + bias) * w), C[:, 2*H*hd:] = A W^T + bias.
  * hd in {32, 64}; the pre-norm values are rounded to dtype first, so the result equals od_gemm_nt + od_qk_norm_rope.

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -78,6 +79,7 @@ class DenoiserEngine:
         # (the sampler's hipGraph) is stale from then on
         self.generation = 0
         self._attn_aux = None
+        self._vendor = None
 
     # ------------------------------------------------------------------ parameters
     def P(self, name: str) -> torch.Tensor:
@@ -136,6 +138,18 @@ class DenoiserEngine:
 
     def W(self, name: str, T: bool = False) -> torch.Tensor:
         return self._packed[name + (".T" if T else "")]
+
+    def plain_gemm(self, A: torch.Tensor, W: torch.Tensor, bias, C: torch.Tensor):
+        """C = A W^T (+ bias), no epilogue: the four long-K, N <= 512 products of a layer at training size go to the vendor library's
+        kernel (20-27 % ahead of gemm_nt_big_kernel there, profiles/r03_gemm_vs_vendor.txt; ops.VendorGemm), everything else — and
+        everything when the library cannot be bound or declines — to od_gemm_nt."""
+        if (A.is_cuda and A.dtype == torch.bfloat16 and A.shape[0] >= 32768 and W.shape[0] <= 512 and A.shape[1] >= 1024
+                and os.environ.get("OD_VENDOR_GEMM", "1") != "0"):
+            if self._vendor is None:
+                self._vendor = ops.VendorGemm(A.device)
+            if self._vendor.gemm_nt(A, W, bias, C):
+                return
+        ops.gemm_nt(A, W, bias, C, x3=self.x3)
 
     # ------------------------------------------------------------------ plan / workspace
     def plan(self, B: int, L: int, Ba: int, dtype: torch.dtype, train: bool, x3: bool = False):
@@ -225,7 +239,7 @@ class DenoiserEngine:
             ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, self.H, L, self.hd,
                                1.0 / math.sqrt(self.hd), x3=self.x3, q_prescaled=True)
             ao = self.lbuf("ao", i, (M, D))
-            ops.gemm_nt(y, self.W(p + "attn.out_proj"), self.P(p + "attn.out_proj.bias"), ao, x3=self.x3)
+            self.plain_gemm(y, self.W(p + "attn.out_proj"), self.P(p + "attn.out_proj.bias"), ao)
             # --- gate + residual of the attention branch and norm + FiLM of the feed-forward branch, one pass
             x_mid = self.lbuf("x_mid", i, (M, D))
             h2 = self.lbuf("h2", i, (M, D))
@@ -244,7 +258,7 @@ class DenoiserEngine:
             if self._drop_active():                           # nn.Dropout1d, training mode only (swiglu.py:23,30)
                 ops.scale_channels(hh, self.draw_dropout_mask(i), B, L)
             fo = self.lbuf("fo", i, (M, D))
-            ops.gemm_nt(hh, self.W(p + "ffn.proj_o"), self.P(p + "ffn.proj_o.bias"), fo, x3=self.x3)
+            self.plain_gemm(hh, self.W(p + "ffn.proj_o"), self.P(p + "ffn.proj_o.bias"), fo)
             # next layer input (at inference x_in.0 / x_in.1 ping-pong), together with the next layer's h1
             x = self.buf(f"x_in.{i + 1}", (M, D)) if self.train else self.buf(f"x_in.{(i + 1) & 1}", (M, D))
             if i + 1 < self.depth:
@@ -368,11 +382,11 @@ class DenoiserEngine:
             ops.gemm_tn(dvg[:, :Hp], hdw, gw[:Hf], n_cols=Hf, k_cols=D, dbias=gb[:Hf])
             ops.gemm_tn(dvg[:, Hp:], hdw, gw[Hf:], n_cols=Hf, k_cols=D, dbias=gb[Hf:])
             if self.radius > 0:
-                ops.gemm_nt(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dtmp)
+                self.plain_gemm(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dtmp)
                 ops.dwconv_bwd(t[f"h2.{i}"], self.P(p + "ffn.proj_vg.0.weight"), dtmp, dbr,
                                self.G(p + "ffn.proj_vg.0.weight"), self.G(p + "ffn.proj_vg.0.bias"), B, L, self.ksize)
             else:
-                ops.gemm_nt(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dbr)
+                self.plain_gemm(dvg, self.W(p + "ffn.proj_vg.1", T=True), None, dbr)
             ops.rmsnorm_film_bwd(t[f"x_mid.{i}"], t[f"inv3.{i}"], ssg2, dbr, dx, dssg2, B, L)
             # ---- attention branch
             ops.rmsnorm_gate_residual_bwd(t[f"ao.{i}"], t[f"inv2.{i}"], ssg1, dx, dbr, dssg1, B, L)
@@ -380,7 +394,7 @@ class DenoiserEngine:
             ops.gemm_nt(dbr, self.W(p + "attn.out_proj", T=True), None, dy)
             self.attn_bwd_launch(i, dy, delta, dqkv)
             ops.gemm_tn(dqkv, t[f"h1.{i}"], self.G(p + "attn.qkv_proj.weight"), dbias=self.G(p + "attn.qkv_proj.bias"))
-            ops.gemm_nt(dqkv, self.W(p + "attn.qkv_proj", T=True), None, dtmp)      # d h1 (== d cl)
+            self.plain_gemm(dqkv, self.W(p + "attn.qkv_proj", T=True), None, dtmp)      # d h1 (== d cl)
             ops.gemm_tn(dtmp, a, self.G(p + "proj_cl.weight"), dbias=self.G(p + "proj_cl.bias"))
             ops.gemm_nt(dtmp, self.W(p + "proj_cl", T=True), None, da, accumulate=(i != self.depth - 1))
             ops.rmsnorm_film_bwd(t[f"x_in.{i}"], t[f"inv1.{i}"], ssg1, dtmp, dx, dssg1, B, L)

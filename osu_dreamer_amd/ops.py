@@ -6,6 +6,7 @@ Activations are frame-major 2-D tensors [M = B*L, C] (see csrc/od_common.h).
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -72,6 +73,46 @@ def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False, x3=False):
     _f32(bias)
     _lib.lib().od_gemm_nt(code, _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
                           epilogue, int(accumulate), _stream(A))
+
+
+class VendorGemm:
+    """Handle of the vendor-library GEMM path (od_vendor_gemm_create: hipBLASLt bound at run time) plus the workspace it may use.
+    `available` is False when the library could not be bound — callers then stay on od_gemm_nt."""
+
+    WORKSPACE_BYTES = 64 << 20
+
+    def __init__(self, device):
+        import ctypes
+        self.handle = ctypes.c_void_p()
+        self.workspace = None
+        path = os.environ.get("OD_HIPBLASLT_LIB", "/opt/rocm/lib/libhipblaslt.so")
+        rc = _lib.lib().cdll.od_vendor_gemm_create(ctypes.byref(self.handle), path.encode())
+        self.available = rc == 0 and bool(self.handle)
+        if self.available:
+            self.workspace = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+
+    def gemm_nt(self, A, W, bias, C) -> bool:
+        """C = A W^T (+ bias) through the library; False (nothing launched) when it declines the shape."""
+        if not self.available:
+            return False
+        M, K = A.shape
+        N = W.shape[0]
+        assert W.shape[1] == K and tuple(C.shape) == (M, N) and A.dtype == W.dtype == C.dtype
+        _f32(bias)
+        rc = _lib.lib().cdll.od_gemm_nt_vendor(self.handle, dt_code(A.dtype), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
+                                               _p(self.workspace), self.workspace.numel(), _stream(A))
+        return rc == 0
+
+    def close(self):
+        if self.handle:
+            _lib.lib().od_vendor_gemm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def gemm_nt_qkrope(A, W, bias, C, wq, wk, table, L, H, hd, eps, x3=False, q_scale=1.0):

@@ -91,6 +91,39 @@ def test_gemm_nt_qkrope_equals_gemm_then_rope(dev, dtype, H, hd, L, B, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,with_bias", [(32768, 512, 1024, True), (40000, 512, 1408, True), (32768, 512, 3072, False), (65536, 512, 2816, False)])
+def test_gemm_nt_vendor_equals_own_kernel(M, N, K, with_bias):
+    """The vendor-library path of the plain long-K GEMMs (od_gemm_nt_vendor: hipBLASLt bound at run time) against od_gemm_nt and
+    against torch: same operands, same leading dimensions (column sub-views included), bias in the epilogue.  Skipped when the
+    library cannot be bound on the box (the engine then stays on od_gemm_nt)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    from osu_dreamer_amd import _lib
+    _lib._lib = None
+    _lib.lib()
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    vg = ops.VendorGemm(dev)
+    if not vg.available:
+        pytest.skip("hipBLASLt could not be bound")
+    g = torch.Generator().manual_seed(41)
+    Af = mk((M, K + 64), g, dev, bf)
+    A = Af[:, 32:32 + K]                                   # a column sub-view: leading dimension K + 64
+    W = mk((N, K), g, dev, bf, scale=0.05)
+    b = mk((N,), g, dev) if with_bias else None
+    C1, C2 = torch.zeros(M, N, dtype=bf, device=dev), torch.zeros(M, N, dtype=bf, device=dev)
+    assert vg.gemm_nt(A, W, b, C1)
+    ops.gemm_nt(A, W, b, C2)
+    ref = A.float() @ W.float().t() + (b if with_bias else 0)
+    assert float((C1.float() - ref).norm() / ref.norm()) < 5e-3 and float((C2.float() - ref).norm() / ref.norm()) < 5e-3
+    assert float((C1.float() - C2.float()).norm() / ref.norm()) < 5e-3
+    # a shape class the host never routes there still works or is declined cleanly (never a wrong result)
+    C3 = torch.zeros(128, N, dtype=bf, device=dev)
+    if vg.gemm_nt(A[:128], W, b, C3):
+        assert float((C3.float() - ref[:128]).norm() / ref[:128].norm()) < 5e-3
+    vg.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,K", [(512, 1024), (512, 1408), (3072, 512)])
 def test_gemm_nt_sampler_rows(N, K):
     """od_gemm_nt at the sampler's M = 4 x 1115 = 4460 rows, bf16 and fp32-as-3-x-bf16 with a pre-split weight, against torch."""

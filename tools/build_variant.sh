@@ -8,7 +8,7 @@ name=$1; flags=$2; shift 2 || true
 srcs=${@:-attn}
 out=../../gpurun_variants; mkdir -p $out/obj_$name
 objs=""
-for s in gemm rowops misc heads optim attn style latent comm; do
+for s in gemm rowops misc heads optim attn style latent comm vendor_gemm; do
   if [[ " $srcs " == *" $s "* ]]; then
     extra=""; [ "$s" = "attn" ] && extra="-ffinite-math-only ${ATTN_SLP--fno-slp-vectorize}"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra $flags -c $s.hip -o $out/obj_$name/$s.o
