@@ -85,11 +85,31 @@ class VendorGemm:
         import ctypes
         self.handle = ctypes.c_void_p()
         self.workspace = None
-        path = os.environ.get("OD_HIPBLASLT_LIB", "/opt/rocm/lib/libhipblaslt.so")
-        rc = _lib.lib().cdll.od_vendor_gemm_create(ctypes.byref(self.handle), path.encode())
+        # PyTorch's own copy: it is already loaded in this process, and a second hipBLASLt (the ROCm tree's) cannot be — its rocRoller
+        # symbols clash with the loaded one's (observed on the MI355X image: dlopen fails with an undefined rocRoller symbol)
+        path = os.environ.get("OD_HIPBLASLT_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "libhipblaslt.so")
+        rc = _lib.lib().cdll.od_vendor_gemm_create(ctypes.byref(self.handle), path.encode()) if os.path.exists(path) else -1
         self.available = rc == 0 and bool(self.handle)
         if self.available:
             self.workspace = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+            self.available = self._self_test(device)
+
+    def _self_test(self, device) -> bool:
+        """The library is bound through a header of another release than the binary (ROCm's header, PyTorch's library): one small product
+        with a bias is checked against od_gemm_nt before the path is trusted.  Any disagreement turns the path off."""
+        g = torch.Generator().manual_seed(0)
+        A = torch.randn(256, 1024, generator=g).to(torch.bfloat16).to(device)
+        W = (torch.randn(512, 1024, generator=g) * 0.05).to(torch.bfloat16).to(device)
+        b = torch.randn(512, generator=g).to(device)
+        C1 = torch.zeros(256, 512, dtype=torch.bfloat16, device=device)
+        C2 = torch.zeros_like(C1)
+        self.available = True
+        ok = self.gemm_nt(A, W, b, C1)
+        gemm_nt(A, W, b, C2)
+        if not ok:
+            return False
+        err = float((C1.float() - C2.float()).norm() / C2.float().norm())
+        return err < 1e-2
 
     def gemm_nt(self, A, W, bias, C) -> bool:
         """C = A W^T (+ bias) through the library; False (nothing launched) when it declines the shape."""
