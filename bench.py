@@ -151,8 +151,10 @@ def roofline_of_dominant_kernel(tr, B, L):
     dy, dqkv, delta = t["d.y"], t["d.qkv"], t["d.delta"]
     scale = 1 / math.sqrt(hd)
 
-    def bwd():
-        eng.attn_bwd_launch(i, dy, delta, dqkv)       # exactly as the step launches it (q / k norm + RoPE backward in its epilogues)
+    fused = eng.fused_rope_bwd()
+
+    def bwd():       # exactly as the step launches it: delta, then dK/dV and dQ side by side (od_flash_attn_bwd_aux)
+        eng.attn_bwd_launch(i, dy, delta, dqkv, core_only=True)
 
     def fwd():
         ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, H, L, hd, scale, q_prescaled=True)
@@ -163,7 +165,8 @@ def roofline_of_dominant_kernel(tr, B, L):
     ach_bwd = BWD_PASSES_ALGORITHMIC * unit / t_bwd / 1e12
     ach_fwd = 2 * unit / t_fwd / 1e12
     return {
-        "bound": "mfma", "kernel": "od_flash_attn_bwd_qkrope (attention backward of one layer, q/k norm + RoPE backward in its epilogues)",
+        "bound": "mfma", "kernel": ("od_flash_attn_bwd_qkrope (attention backward of one layer, q/k norm + RoPE backward in its epilogues)" if fused else
+                                   "od_flash_attn_bwd (attention backward of one layer: delta, then dK/dV and dQ on two streams)"),
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "ms_per_launch": round(t_bwd * 1e3, 3),

@@ -286,9 +286,10 @@ class DenoiserEngine:
         import os
         return self.dtype == torch.bfloat16 and self.hd == 64 and os.environ.get("OD_FUSED_ROPE_BWD", "0") == "1"
 
-    def attn_bwd_launch(self, i: int, dy: torch.Tensor, delta: torch.Tensor, dqkv: torch.Tensor):
-        """The backward of layer i's attention core + q / k norm + RoPE exactly as `backward` launches it (also what bench.py times
-        alone): dy = gradient of the attention output, dqkv <- gradient of the qkv projection; norm weight gradients accumulate."""
+    def attn_bwd_launch(self, i: int, dy: torch.Tensor, delta: torch.Tensor, dqkv: torch.Tensor, core_only: bool = False):
+        """The backward of layer i's attention core + q / k norm + RoPE exactly as `backward` launches it: dy = gradient of the attention
+        output, dqkv <- gradient of the qkv projection; norm weight gradients accumulate.  `core_only` (bench.py's roofline leg): just
+        od_flash_attn_bwd (delta, dK/dV, dQ) as the step launches it, without the separate norm + RoPE backward pass that follows it."""
         t, dh, p = self.ws.t, self.dh, f"net.layers.{i}."
         qk, qkv, y, lse = t[f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
         wq, wk = self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight")
@@ -303,7 +304,8 @@ class DenoiserEngine:
             self._attn_aux = ops.AttnAux()                  # side stream + events: the dQ kernel runs beside the dK/dV kernel
         ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
                            dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, scale, q_prescaled=True, aux=self._attn_aux)
-        ops.qk_norm_rope_bwd(qkv, wq, wk, t["rope"], dqk, dqkv, gq, gk, self.B, self.L, self.H, self.hd, FP32_EPS, q_scale=self.q_scale)
+        if not core_only:
+            ops.qk_norm_rope_bwd(qkv, wq, wk, t["rope"], dqk, dqkv, gq, gk, self.B, self.L, self.H, self.hd, FP32_EPS, q_scale=self.q_scale)
 
     # ---- nn.Dropout1d(p) of the SwiGLU hidden state: a (B, Hp) factor per layer, 0 or 1 / (1 - p), drawn by torch's generator
     #      (as the reference's mask is) when the module is in training mode; `hh` is stored masked, so proj_o's weight gradient
