@@ -472,6 +472,247 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict
     }
 }
 
+// ---- NT, large-M variant with FOUR waves (round 3): 256x256 block tile, one wave per SIMD, each wave a 128 x 128 sub-tile -----------
+// The board runs these GEMMs at its power limit (1400 W, tools/power_probe.py): what decides the rate is how few clock cycles the work takes
+// (the governor trades the cycles saved for a lower clock and voltage), i.e. how close the MFMA pipe is to always busy.  The vendor
+// library's kernel for the long-K shapes — same macro tile, same fetch volume, 20-27 % faster than gemm_nt_big_kernel — gets there with a
+// loop rather than a tile (its disassembly: 4 waves, 256 accumulator registers, fragments of two slabs in VGPRs, LDS-DMA, counted waits):
+//   * 128 x 128 per wave: 16 fragment reads per 64 MFMAs instead of 12 per 32;
+//   * one wave per SIMD with 64 independent accumulators issues MFMAs back to back; an MFMA leaves ~12 cycles of issue shadow, enough for ONE
+//     cheap instruction — so every fragment read and every DMA instruction sits alone between two MFMAs (tools/ubench/barrier_cost.hip:
+//     64 MFMAs 1044 cycles; + 16 ds_read_b128 1220; + 8 DMA pieces as s_mov m0 / MFMA / buffer_load 1244, as s_mov, s_nop, load 1340);
+//   * the fetch must move whole 128-byte lines per DMA piece (tools/ubench/stream_cost.hip: pieces of 16 rows x 64 B, the natural shape
+//     for a ring of 32-deep slab stages, run the same skeleton at 2095 cycles per slab instead of 1612 — the L1 fetches the line twice).
+// This kernel is that loop in HIP.  Two 64-KiB stages (a 64-deep K tile each, 128-byte rows); per tile of 128 MFMAs and per wave:
+//   MFMA   0.. 31   the tile's slab-1 fragments go to register set 1 (a read in front of every 2nd MFMA: R_AT / 16);
+//   RELEASE barrier (the stage is in everybody's registers) at 32;
+//   MFMA  33..123   the wave's 16 DMA pieces of tile kt + 2 into the released stage, one around every 6th MFMA;
+//   LANDED  barrier at 88: vmcnt(10) — everything but this tile's first ten pieces, i.e. all of tile kt + 1 — then
+//   MFMA  88..118   slab-0 fragments of tile kt + 1 from the other stage to register set 0 (every 2nd MFMA).
+// A fetch has 0.7 - 1.4 tile times to land.  asm MFMAs with "a" constraints keep the 256 accumulators in AGPRs (the builtin form compiled
+// to ~6 v_accvgpr copies per MFMA); LDS-DMA through a buffer descriptor (rows past M / N read as zero; past the last tile the
+// descriptor has length 0: no fetch, same wait counts).  bf16, K % 128 == 0, N % 8 == 0.
+#ifndef OD_W4_PIN
+#define OD_W4_PIN 1
+#endif
+#ifndef OD_W4_R_AT
+#define OD_W4_R_AT 32          // RELEASE barrier in front of this MFMA; the slab-1 reads sit in front of MFMAs 0, 2, .. below it
+#endif
+#ifndef OD_W4_RD1_BY
+#define OD_W4_RD1_BY 24        // the slab-1 reads sit in front of MFMAs 0, 1, 3, 4, ... below this
+#endif
+#ifndef OD_W4_L_AT
+#define OD_W4_L_AT 88          // LANDED barrier in front of this MFMA
+#endif
+#ifndef OD_W4_DMA_EVERY
+#define OD_W4_DMA_EVERY 6
+#endif
+#ifndef OD_W4_X
+#define OD_W4_X 0          // timing experiments only (wrong results): 2 no loop fragment reads, 4 no loop barriers, 8 no loop waits, 16 no fetch
+#endif
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ C, int ldc,
+                                                            int M, int N, int K, int nt_store) {
+    using T = bf16_t;
+    constexpr int TM = 256, TN = 256, STG = 65536;       // stage: A 32 KiB (256 rows x 128 B) then W 32 KiB
+    OD_DYN_SMEM(smem);
+    // PERSISTENT: one workgroup per CU (grid = 256) walks output tiles v = 0, 1, ... — the tile a grid of gridDim.x * (v + 1) blocks would
+    // give block blockIdx.x + gridDim.x * v under tile_of_block's XCD-aware order — and the operand pipeline runs across the tile
+    // boundary: the last two K tiles of an output tile fetch the first two of the next one, whose first fragments are in registers when the
+    // epilogue starts.  A cold start (fetch latency, ~2 us) and a drained pipeline per output tile cost the non-persistent form ~8 % at
+    // K = 3072 and far more at K = 512.
+    const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    auto tile_at = [&](int v, int& m0_, int& n0_) {
+        const int sl = slot0 + slots * v;
+        const int tm = (sl / tiles_n) * 8 + xcd;
+        m0_ = tm * TM; n0_ = (sl % tiles_n) * TN;
+        return tm < tiles_m;
+    };
+    int m0, n0;
+    if (!tile_at(0, m0, n0)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = od_uniform(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 15, g = lane >> 4;
+    const int nk = K / 64;
+
+    // The accumulators START at the bias: lane (x, g) holds, for output row m0 + wm*128 + 16 j + x, the columns n0 + wn*128 + 32 p + 8 g .. + 7
+    // (acc[2p][j][0..3], acc[2p+1][j][0..3]) — the same eight bias values for every j.  (A bias load in the epilogue would sit behind the
+    // epilogue's own stores in the VMEM counter and wait for every one of them.)
+    f32x4 acc[8][8];           // [n tile i (pair i>>1, half i&1)][m tile j]
+    auto load_bias = [&](int n0_, f32x4 (&bv)[8]) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int gn = n0_ + wn * 128 + 32 * p + 8 * g;
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) t[e] = 0.f;
+            if (bias && gn < N) od_ld8(bias + gn, t);
+#pragma unroll
+            for (int r = 0; r < 4; r++) { bv[2 * p][r] = t[r]; bv[2 * p + 1][r] = t[4 + r]; }
+        }
+    };
+    {
+        f32x4 bv[8];
+        load_bias(n0, bv);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[i][j] = bv[i];
+    }
+
+    // staging: waves 0, 1 stream the A tile (32 pieces of 8 rows x 128 B), waves 2, 3 the W tile; 16 pieces per wave and tile.
+    // LDS rows are 128 B with the 16-byte slots XOR-swizzled by a per-row key.  A rows: key = row & 7 (a fragment read covers 16 consecutive
+    // rows).  W rows: a fragment covers rows 8 (x >> 2) + 4 h + (x & 3) — under row & 7 the lanes x and x + 12 (and x + 4, x + 8) of one
+    // ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) meet in the same banks, a 2-way conflict on every W read — so the key takes row bits
+    // 1, 3, 4 instead: ((row >> 1) & 1) | (((row >> 3) & 3) << 1), which makes each group's 16 lanes cover all 64 banks once.
+    const bool isw = wave >= 2;
+    const int ld = isw ? ldw : lda, lim = isw ? N : M;
+    auto srd_of = [&](int m0_, int n0_, bool valid) {                       // this wave's operand rows of the tile at (m0_, n0_)
+        const int r0 = isw ? n0_ : m0_;
+        const long avail = (long)(lim - r0 - 1) * ld + K;                   // elements to the end of the last valid row
+        return od_make_srd((isw ? W : A) + (size_t)r0 * ld, valid ? (unsigned)((avail > 0 ? avail : 0) * 2) : 0u);
+    };
+    od_srd_t srd_cur = srd_of(m0, n0, true), srd_nxt = srd_cur, srd = srd_cur;
+    const int prow = lane >> 3;
+    unsigned voff4[4];                                                       // by piece & 3 (the W key depends on it)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int key = isw ? (((prow >> 1) & 1) | (q << 1)) : prow;
+        voff4[q] = (unsigned)((((wave & 1) * 16 + q) * 8 + prow) * ld * 2 + (((lane & 7) ^ key) << 4));
+    }
+    const unsigned lds_mine = od_lds_addr(smem) + (isw ? 32768u : 0u) + (unsigned)(wave & 1) * 16384u;
+    const unsigned piece_stride = (unsigned)(8 * ld * 2);
+    // piece i of this wave's 16: rows ((wave & 1) * 16 + i) * 8 ..., i = 4 t + q -> voff4[q], t * 4 pieces further down
+    int offA[2], offW[2];
+    {
+        const int wkey = ((x >> 1) & 1) | ((x >> 2) << 1);
+        const int wrow = wn * 128 + 8 * (x >> 2) + (x & 3);
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+            offA[sl] = (wm * 128 + x) * 128 + (((sl * 4 + g) ^ (x & 7)) << 4);          // + j * 2048
+            offW[sl] = 32768 + wrow * 128 + (((sl * 4 + g) ^ wkey) << 4);              // + (i & 1) * 512 + (i >> 1) * 4096
+        }
+    }
+    od_frag<T> fa[2][8], fw[2][8];                        // [slab = register set][tile]
+    auto rdA = [&](const unsigned char* st, int sl, int j) { fa[sl][j].v = *(const s16x8*)(st + offA[sl] + j * 2048); };
+    auto rdW = [&](const unsigned char* st, int sl, int i) { fw[sl][i].v = *(const s16x8*)(st + offW[sl] + (i & 1) * 512 + (i >> 1) * 4096); };
+    // MFMA n of a slab: eight consecutive ones share the W fragment and walk the A-matrix fragments; the reads come in the order of first use
+    auto mma_one = [&](int sl, int n) {
+        const int i = n >> 3, j = n & 7;
+#if defined(OD_EMU)
+        acc[i][j] = od_mma(fw[sl][i], fa[sl][j], acc[i][j]);
+#else
+        // an accumulator is reused 64 MFMAs later: no back-to-back dependency
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fw[sl][i].v), "v"(fa[sl][j].v));
+#endif
+    };
+    auto rd_seq = [&](const unsigned char* st, int sl, int r) {
+        if (r == 0) rdW(st, sl, 0); else if (r < 9) rdA(st, sl, r - 1); else rdW(st, sl, r - 8);
+    };
+#if OD_W4_PIN
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define W4_FENCE() ((void)0)
+#endif
+
+    // prologue: tiles 0 and 1 in flight, tile 0 landed, its slab-0 fragments in register set 0
+#pragma unroll
+    for (int t = 0; t < 2; t++) {                          // nk >= 2
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            od_buffer_lds16_at(srd_cur, voff4[i & 3], (unsigned)t * 128u + (unsigned)(i >> 2) * 4u * piece_stride, lds_mine + (unsigned)t * STG + (unsigned)i * 1024u);
+    }
+    OD_WAIT_VMCNT(16);
+    od_barrier_raw();
+#pragma unroll
+    for (int r = 0; r < 16; r++) rd_seq(smem, 0, r);
+
+    constexpr int DMA0 = OD_W4_R_AT + 1;                                        // first DMA slot
+    constexpr int BEFORE_L = (OD_W4_L_AT - DMA0 + OD_W4_DMA_EVERY - 1) / OD_W4_DMA_EVERY;   // pieces issued in front of the LANDED barrier
+    static_assert(OD_W4_RD1_BY >= 24 && OD_W4_RD1_BY <= OD_W4_R_AT && DMA0 + 15 * OD_W4_DMA_EVERY < 128 && OD_W4_L_AT + 30 < 128, "schedule does not fit the tile");
+    auto tile = [&](int kt, const int xs) {
+        const unsigned char* X = smem + xs * STG;
+        const unsigned char* Y = smem + (xs ^ 1) * STG;
+        const unsigned dst = lds_mine + (unsigned)xs * STG;
+        const bool wrap = kt + 2 >= nk;                    // the fetch belongs to the next output tile (or to nothing: a descriptor of length 0)
+        const unsigned so = (unsigned)(wrap ? kt + 2 - nk : kt + 2) * 128u;
+#pragma clang loop unroll(full)
+        for (int n = 0; n < 128; n++) {
+            if (n == OD_W4_R_AT) {
+                if (!(OD_W4_X & 8)) OD_WAIT_LGKMCNT(0);
+                if (!(OD_W4_X & 4)) od_barrier_raw();
+                srd = wrap ? srd_nxt : srd_cur;
+                if (OD_W4_X & 16) od_srd_set_bytes(srd, 0u);
+            }
+            if (n == OD_W4_L_AT) {
+                if (!(OD_W4_X & 8)) {
+#define W4_VM(c) else if (BEFORE_L == c) OD_WAIT_VMCNT(c)
+                    if (BEFORE_L >= 16) OD_WAIT_VMCNT(16);
+                    W4_VM(15); W4_VM(14); W4_VM(13); W4_VM(12); W4_VM(11); W4_VM(10); W4_VM(9); W4_VM(8); W4_VM(7); W4_VM(6); W4_VM(5); W4_VM(4);
+                    else OD_WAIT_VMCNT(0);
+#undef W4_VM
+                }
+                if (!(OD_W4_X & 4)) od_barrier_raw();
+            }
+            const bool d = n >= DMA0 && (n - DMA0) % OD_W4_DMA_EVERY == 0 && (n - DMA0) / OD_W4_DMA_EVERY < 16;
+            const int q = (n - DMA0) / OD_W4_DMA_EVERY;
+            if (d) od_dma_set_dst(dst + (unsigned)q * 1024u);
+            if (!(OD_W4_X & 2)) {
+                // 16 reads in front of MFMAs 0, 1, 3, 4, 6, ... (two per three) of the first OD_W4_RD1_BY: the last one is well ahead of the barrier
+                if (n < OD_W4_RD1_BY && (n % 3 != 2) && (n / 3) * 2 + n % 3 < 16) rd_seq(X, 1, (n / 3) * 2 + n % 3);
+                if (n >= OD_W4_L_AT && (n - OD_W4_L_AT) % 2 == 0 && (n - OD_W4_L_AT) / 2 < 16) rd_seq(Y, 0, (n - OD_W4_L_AT) / 2);
+            }
+            mma_one(n >> 6, n & 63);
+            if (d) od_buffer_lds16_m0(srd, voff4[q & 3], so + (unsigned)(q >> 2) * 4u * piece_stride);
+            W4_FENCE();
+        }
+    };
+    for (int v = 0;; v++) {
+        int m1, n1;
+        const bool more = tile_at(v + 1, m1, n1);
+        srd_nxt = srd_of(more ? m1 : 0, more ? n1 : 0, more);
+        for (int kt = 0; kt < nk; kt += 2) {               // K % 128 == 0 (launcher)
+            tile(kt, 0);
+            tile(kt + 1, 1);
+        }
+#if !defined(OD_EMU)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the epilogue reads the accumulators (asm MFMAs are invisible to the hazard pass)
+#endif
+        // epilogue: the next tile's bias first (a load issued after the stores would wait for them), then one 16-byte store per tile pair
+        // straight from the accumulators, which restart at that bias
+        f32x4 bv[8];
+        load_bias(more ? n1 : n0, bv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int gm = m0 + wm * 128 + j * 16 + x;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int gn = n0 + wn * 128 + 32 * p + 8 * g;
+                float v8[8];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { v8[r] = acc[2 * p][j][r]; v8[4 + r] = acc[2 * p + 1][j][r]; }
+                acc[2 * p][j] = bv[2 * p]; acc[2 * p + 1][j] = bv[2 * p + 1];
+                if (gm >= M || gn >= N) continue;
+                T* dst = C + (size_t)gm * ldc + gn;
+                if (EPI == OD_EPI_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v8[e] = od_silu(v8[e]);
+                }
+                if (nt_store) od_st8_nt(dst, v8); else od_st8(dst, v8);
+            }
+        }
+        if (!more) break;
+#if !defined(OD_EMU)
+        asm volatile("s_nop 7" ::: "memory");               // accumulator writes (zeroing) before the next asm MFMA reads them
+#endif
+        m0 = m1; n0 = n1; srd_cur = srd_nxt;
+    }
+#undef W4_FENCE
+    OD_WAIT_VMCNT(0);
+}
+
 // 256-byte-row tile addressing for the TN slabs: XOR at 32-byte granularity (slot PAIRS), because a
 // transpose read touches two adjacent 16-byte slots of 8 different rows per 32-lane group.
 __device__ __forceinline__ int tn_off(int row, int byte) {
@@ -830,6 +1071,18 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
         // evict the W / A lines the next tiles re-read, and this loop is bound by fetch latency x outstanding misses
         // (profiles/r02l_gemm_fetch_bound.txt): +7..12 % at N = 1024..2816, +2.5 % at 3072; at N = 512 (2 column tiles) it costs 3 %.
         const int nt_store = !accumulate && N >= OD_GEMM_NT_STORE_MIN_N;
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            static const int w4 = od_env_int("OD_NT_W4", 1);
+            static const int w4_min_k = od_env_int("OD_NT_W4_MIN_K", 0);
+            if (w4 && epi != OD_EPI_QKROPE && !accumulate && K >= w4_min_k && K % 128 == 0) {
+                if (epi == OD_EPI_SILU)
+                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_SILU>), dim3(grid2 < 256 ? grid2 : 256), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
+                else
+                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_NONE>), dim3(grid2 < 256 ? grid2 : 256), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
+                OD_CHECK_LAUNCH();
+                return 0;
+            }
+        }
         if (epi == OD_EPI_QKROPE) {
             if constexpr (std::is_same<T, bf16_t>::value)
                 OD_LAUNCH_DYN((gemm_nt_big_kernel<T, OD_EPI_QKROPE>), dim3(grid2), dim3(512), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, 0, (rp.qk_out ? nt_store : 0), rp);

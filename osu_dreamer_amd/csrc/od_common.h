@@ -258,6 +258,7 @@ __device__ __forceinline__ void od_glds16(const void* g, void* lds) {
 #if defined(OD_EMU)
 struct od_srd_t { const unsigned char* base; unsigned bytes; };
 __device__ __forceinline__ od_srd_t od_make_srd(const void* base, unsigned bytes) { return od_srd_t{(const unsigned char*)base, bytes}; }
+__device__ __forceinline__ void od_srd_set_bytes(od_srd_t& r, unsigned bytes) { r.bytes = bytes; }
 __device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsigned soff, void* lds) {
     // the hardware range-checks per DWORD: the in-range dwords of a chunk that straddles the end of the buffer are loaded
     alignas(16) unsigned char tmp[16] = {0};
@@ -269,15 +270,18 @@ __device__ __forceinline__ int od_uniform(int x) { return x; }
 // the emulator's "LDS address" is an offset from the dynamic shared array
 __device__ __forceinline__ unsigned od_lds_addr(const void* p) { return (unsigned)((const unsigned char*)p - emu::dyn_smem()); }
 __device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
-    od_buffer_lds16(r, voff, soff, emu::dyn_smem() + lds_addr);
+    od_buffer_lds16(r, voff, soff, emu::dyn_smem() + (long)(int)lds_addr);     // signed: a static __shared__ array may lie below the dynamic one
 }
 __device__ __forceinline__ void od_buffer_lds16_at_nt(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) { od_buffer_lds16_at(r, voff, soff, lds_addr); }
+__device__ __forceinline__ unsigned& od_emu_m0() { static thread_local unsigned m0 = 0; return m0; }
+__device__ __forceinline__ void od_dma_set_dst(unsigned lds_addr) { od_emu_m0() = lds_addr; }
+__device__ __forceinline__ void od_buffer_lds16_m0(od_srd_t r, unsigned voff, unsigned soff) { od_buffer_lds16_at(r, voff, soff, od_emu_m0()); }
 // one dword per lane: lane i's 4 bytes land at lds_addr + 4*i (zero past the end of the buffer)
 __device__ __forceinline__ void od_buffer_lds4_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
     unsigned v = 0;
     const unsigned off = voff + soff;
     if (off + 4 <= r.bytes) memcpy(&v, r.base + off, 4);
-    memcpy(emu::dyn_smem() + lds_addr + 4 * emu::lane_id(), &v, 4);
+    memcpy(emu::dyn_smem() + (long)(int)lds_addr + 4 * emu::lane_id(), &v, 4);
 }
 #else
 // The DMA is issued from inline asm, on purpose: hipcc treats a builtin LDS-DMA as a pending LDS write and puts
@@ -294,6 +298,7 @@ __device__ __forceinline__ od_srd_t od_make_srd(const void* base, unsigned bytes
     r[3] = 0x00020000u;
     return r;
 }
+__device__ __forceinline__ void od_srd_set_bytes(od_srd_t& r, unsigned bytes) { r[2] = __builtin_amdgcn_readfirstlane(bytes); }
 __device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsigned soff, void* lds) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds);
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(m0v) : "memory", "m0");
@@ -303,6 +308,12 @@ __device__ __forceinline__ void od_buffer_lds16(od_srd_t r, unsigned voff, unsig
 __device__ __forceinline__ unsigned od_lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p; }
 __device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff), "s"(lds_addr) : "memory", "m0");
+}
+// the same in two halves, for loops that put an MFMA between them (the M0 write needs one wait state before the DMA reads it, and a wave that
+// is alone on its SIMD has no issue slot to spare for an s_nop)
+__device__ __forceinline__ void od_dma_set_dst(unsigned lds_addr) { asm volatile("s_mov_b32 m0, %0" ::"s"(lds_addr) : "memory", "m0"); }
+__device__ __forceinline__ void od_buffer_lds16_m0(od_srd_t r, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(r), "s"(soff) : "memory", "m0");
 }
 // one dword per lane (64 x 4 B = 256 B per wave): lane i's dword lands at lds_addr + 4*i, zero past the end of the buffer
 __device__ __forceinline__ void od_buffer_lds4_at(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) {

@@ -91,7 +91,8 @@ def test_ddp_step_world1_equals_plain_step(pg):
     print(f"plain-vs-plain noise: loss {noise_loss:.2e}, params {noise_p:.2e}, ema {noise_e:.2e}; "
           f"ddp-vs-plain: loss {abs(outs[2][0] - outs[0][0]) / abs(outs[0][0]):.2e}, params {rel(outs[2][1], outs[0][1]):.2e}")
     assert abs(outs[2][0] - outs[0][0]) <= 3 * noise_loss * abs(outs[0][0]) + 2e-4 * abs(outs[0][0])
-    assert rel(outs[2][1], outs[0][1]) <= 3 * noise_p + 1e-5 and rel(outs[2][2], outs[0][2]) <= 3 * noise_e + 1e-5
+    # one plain-vs-plain pair is a noisy estimate of the noise (a handful of AdamW sign flips decide it: 1e-5 .. 6e-5 seen over runs)
+    assert rel(outs[2][1], outs[0][1]) <= 3 * noise_p + 1e-4 and rel(outs[2][2], outs[0][2]) <= 3 * noise_e + 1e-4
 
 
 def test_bench_line_through_the_rccl_path():

@@ -218,6 +218,15 @@ def test_flash_attention_fwd_f32x3(dev, B, H, L, hd):
     assert rel_l2(lse, torch.logsumexp(s, -1).float()) < 1e-5
 
 
+def same_up_to_an_ulp(a, b, frac=2e-3):
+    """bf16 tensors equal except for a small fraction of elements that sit on neighbouring bf16 values (or, where the sum cancels to
+    nearly nothing, differ by the fp32 rounding of its terms)."""
+    a, b = a.float().cpu(), b.float().cpu()
+    diff = (a - b).abs()
+    assert float((diff > 0).float().mean()) < frac
+    assert bool((diff <= torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-5 * float(a.abs().max())).all())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("H,hd,L,B,K", [(4, 64, 150, 2, 64), (2, 64, 70, 2, 64), (4, 32, 33, 3, 96), (6, 64, 130, 3, 128)])
 def test_gemm_nt_qkrope_split_equals_gemm_then_rope(dev, dtype, H, hd, L, B, K):
@@ -238,7 +247,10 @@ def test_gemm_nt_qkrope_split_equals_gemm_then_rope(dev, dtype, H, hd, L, B, K):
     raw = torch.zeros(M, 3 * dh, dtype=dtype, device=dev)
     qk2 = torch.zeros(M, 2 * dh, dtype=dtype, device=dev)
     ops.gemm_nt_qkrope_split(A, W, b, raw, qk2, wq, wk, tab, L, H, hd, eps, q_scale=0.18)
-    assert torch.equal(raw, qkv)
+    if dtype == torch.bfloat16 and M >= 256 and K % 128 == 0:
+        same_up_to_an_ulp(raw, qkv)          # od_gemm_nt takes the 4-wave kernel there (bias first, not last: see the large-M test)
+    else:
+        assert torch.equal(raw, qkv)
     assert rel_l2(qk2.float(), qk.float()) < (2e-6 if dtype == torch.float32 else 3e-3)
 
 
@@ -264,12 +276,14 @@ def test_gemm_nt_qkrope_large_m(B, L, K):
     ops.qk_norm_rope(qkv, wq, wk, tab, qk, B, L, H, hd, eps, q_scale=0.18)
     raw, qk2 = torch.zeros_like(qkv), torch.zeros_like(qk)
     ops.gemm_nt_qkrope_split(A, W, b, raw, qk2, wq, wk, tab, L, H, hd, eps, q_scale=0.18)
-    assert torch.equal(raw, qkv)
+    # od_gemm_nt runs the 4-wave kernel here, whose accumulators START at the bias (the 8-wave kernel under the fused epilogue adds it last):
+    # the fp32 sums differ in their last bit now and then, i.e. a bf16 output may land on the neighbouring value
+    same_up_to_an_ulp(raw, qkv)
     assert float((qk2.float() - qk.float()).norm() / qk.float().norm()) < 3e-3
     assert float((qk2.float() - qk.float()).abs().max()) < 0.1
     fused = torch.zeros_like(qkv)
     ops.gemm_nt_qkrope(A, W, b, fused, wq, wk, tab, L, H, hd, eps, q_scale=0.18)
-    assert torch.equal(fused[:, 2 * dh:], qkv[:, 2 * dh:])
+    assert torch.equal(fused[:, 2 * dh:], raw[:, 2 * dh:])
     assert torch.equal(fused[:, :2 * dh], qk2)
 
 

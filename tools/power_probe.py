@@ -1,0 +1,35 @@
+"""Board power and shader clock while one GEMM variant runs back to back for a few seconds:
+python3 tools/power_probe.py N K own|vendor   (OD_NT_W4=1 selects the 4-wave kernel).  Samples `rocm-smi` while the queue drains."""
+import os, re, subprocess, sys, time
+import torch
+sys.path.insert(0, os.getcwd())
+from osu_dreamer_amd import ops
+
+N, K, which = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+dev, bf, M = torch.device("cuda:0"), torch.bfloat16, 32 * 8192
+g = torch.Generator(device=dev).manual_seed(0)
+A = torch.randn(M, K, device=dev, generator=g).to(bf)
+W = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(bf)
+C = torch.zeros(M, N, dtype=bf, device=dev)
+run = (lambda: torch.matmul(A, W.t(), out=C)) if which == "vendor" else (lambda: ops.gemm_nt(A, W, None, C))
+for _ in range(5):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 4000
+e0.record()
+for _ in range(n):
+    run()
+e1.record()
+samples = []
+t0 = time.time()
+while not e1.query() and time.time() - t0 < 20:
+    o = subprocess.run(["/opt/rocm/bin/rocm-smi", "-P", "-c"], capture_output=True, text=True).stdout
+    p = re.search(r"Power \(W\):\s*([\d.]+)", o)
+    s = re.search(r"sclk clock level:?\s*\d*:?\s*\((\d+)Mhz\)", o)
+    samples.append((p.group(1) if p else "?", s.group(1) if s else "?"))
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / n
+print(f"{which} W4={os.environ.get('OD_NT_W4', '0')} N={N} K={K}: {ms * 1e3:.0f} us/launch, {2.0 * M * N * K / ms / 1e9:.0f} TF/s; (W, MHz) samples: {samples[1:-1][:12]}")
+if not samples or samples[0][0] == "?":
+    print(o[:1500])
