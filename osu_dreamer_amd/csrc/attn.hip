@@ -723,13 +723,32 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
             const f32x4 l4 = *(const f32x4*)(s_lse + t4 * 16 + 4 * g);
             const f32x4 d4 = *(const f32x4*)(s_delta + t4 * 16 + 4 * g);
 
+#ifndef OD_DKV_CHAINS
+#define OD_DKV_CHAINS 0     // 1: the score / dP MFMA chains of the NK key tiles are issued interleaved (a dependent MFMA sits NK * 2 MFMAs behind its
+                            // producer instead of right behind it, no s_nop in front of the exponentials).  Measured SLOWER with two waves per SIMD
+                            // (24.5 vs 24.1 ms per layer, three rounds): the other wave already fills those stalls, and the burst of 12 MFMAs then
+                            // 30 VALU instructions gives it less to interleave with.
+#endif
+            f32x4 sa_[NK], pa_[NK];
+            if constexpr (OD_DKV_CHAINS) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+#pragma unroll
+                    for (int ki = 0; ki < NK; ki++) sa_[ki] = od_mma(fqr[s], fk[ki][s], s == 0 ? l4 : sa_[ki]);
+#pragma unroll
+                    for (int ki = 0; ki < NK; ki++) pa_[ki] = od_mma(fdo[s], fv[ki][s], s == 0 ? d4 : pa_[ki]);
+                }
+            }
 #pragma unroll
             for (int ki = 0; ki < NK; ki++) {
                 f32x4 sa = l4, pa = d4;
+                if constexpr (OD_DKV_CHAINS) { sa = sa_[ki]; pa = pa_[ki]; }
+                else {
 #pragma unroll
-                for (int s = 0; s < NS; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
+                    for (int s = 0; s < NS; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
+                }
                 f32x4 e = sa;
-                if constexpr (!PRE) e = sa * c;
+                if constexpr (!PRE) e = od_mul4s(sa, c);
                 f32x4 p;
 #pragma unroll
                 for (int r = 0; r < 4; r++) p[r] = od_exp2(e[r]);
@@ -739,7 +758,7 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
                     for (int r = 0; r < 4; r++)
                         if (!(kvalid && (qbase + t4 * 16 + 4 * g + r < L))) p[r] = 0.f;
                 }
-                const f32x4 ds = p * pa;
+                const f32x4 ds = od_mul4(p, pa);
                 od_frag_set4(fp[ki][t4 >> 1], t4 & 1, p[0], p[1], p[2], p[3]);
                 od_frag_set4(fds[ki][t4 >> 1], t4 & 1, ds[0], ds[1], ds[2], ds[3]);
             }
@@ -898,7 +917,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
 #pragma unroll
                 for (int s = 0; s < NS; s++) { sa = od_mma(fkr[s], fq[qi][s], sa); pa = od_mma(fvr[s], fdo[qi][s], pa); }
                 f32x4 e = sa;
-                if constexpr (!PRE) e = sa * c;
+                if constexpr (!PRE) e = od_mul4s(sa, c);
                 f32x4 p;
 #pragma unroll
                 for (int r = 0; r < 4; r++) p[r] = od_exp2(e[r]);
@@ -907,7 +926,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
                     for (int r = 0; r < 4; r++)
                         if (kbase + t4 * 16 + 4 * g + r >= L) p[r] = 0.f;
                 }
-                const f32x4 ds = p * pa;
+                const f32x4 ds = od_mul4(p, pa);
                 od_frag_set4(fds[qi][t4 >> 1], t4 & 1, ds[0], ds[1], ds[2], ds[3]);
             }
         }

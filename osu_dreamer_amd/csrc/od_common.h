@@ -145,6 +145,35 @@ __device__ __forceinline__ float od_silu_grad(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 
+// Element-wise product WITHOUT packed-f32 math: beside MFMAs a v_pk_mul_f32 costs the matrix pipe ~16 cycles (tools/ubench/mix_power.hip:
+// 64 MFMAs 446 ns; + 16 v_pk_mul_f32 551 ns; + 32 v_fma_f32 / v_exp_f32 / v_cvt_pk_bf16_f32: 443 - 451 ns), and hipcc turns every
+// f32x4 * f32x4 (and f32x4 * scalar) into two of them.
+#if defined(OD_EMU)
+__device__ __forceinline__ f32x4 od_mul4(f32x4 a, f32x4 b) { return a * b; }
+__device__ __forceinline__ f32x4 od_mul4s(f32x4 a, float b) { return a * b; }
+#else
+// Each product is laundered through an empty asm (no instruction; it only hides from the vector combiner that the four products are lanes
+// of one vector).  The multiply itself stays a compiler-visible v_mul_f32: the wait states between an MFMA and a VALU read of its result are
+// software-managed, and a multiply written AS asm read the MFMA result early (dk, dq wrong).
+__device__ __forceinline__ float od_mul1(float a, float b) {
+    float d = a * b;
+    asm("" : "+v"(d));
+    return d;
+}
+__device__ __forceinline__ f32x4 od_mul4(f32x4 a, f32x4 b) {
+    f32x4 d;
+#pragma unroll
+    for (int r = 0; r < 4; r++) d[r] = od_mul1(a[r], b[r]);
+    return d;
+}
+__device__ __forceinline__ f32x4 od_mul4s(f32x4 a, float b) {
+    f32x4 d;
+#pragma unroll
+    for (int r = 0; r < 4; r++) d[r] = od_mul1(a[r], b);
+    return d;
+}
+#endif
+
 // ---------------------------------------------------------------------------------
 // MFMA fragment abstraction, one shape for both compute types: a 16x16 output tile
 // and a 32-deep K slab.  Each lane holds 8 K-consecutive elements of its row:

@@ -140,11 +140,11 @@ class DenoiserEngine:
         return self._packed[name + (".T" if T else "")]
 
     def plain_gemm(self, A: torch.Tensor, W: torch.Tensor, bias, C: torch.Tensor):
-        """C = A W^T (+ bias), no epilogue: the four long-K, N <= 512 products of a layer at training size go to the vendor library's
-        kernel (20-27 % ahead of gemm_nt_big_kernel there, profiles/r03_gemm_vs_vendor.txt; ops.VendorGemm), everything else — and
-        everything when the library cannot be bound or declines — to od_gemm_nt."""
+        """C = A W^T (+ bias), no epilogue.  od_gemm_nt (the 4-wave persistent kernel at training size) runs these; with OD_VENDOR_GEMM=1 the four
+        long-K, N <= 512 products of a layer go to the vendor library's kernel instead (3-5 % ahead there, behind on every K = 512 shape:
+        profiles/r03u_ab_sustained.txt; ops.VendorGemm), falling back to od_gemm_nt when the library cannot be bound or declines."""
         if (A.is_cuda and A.dtype == torch.bfloat16 and A.shape[0] >= 32768 and W.shape[0] <= 512 and A.shape[1] >= 1024
-                and os.environ.get("OD_VENDOR_GEMM", "1") != "0"):
+                and os.environ.get("OD_VENDOR_GEMM", "0") == "1"):
             if self._vendor is None:
                 self._vendor = ops.VendorGemm(A.device)
             if self._vendor.gemm_nt(A, W, bias, C):

@@ -1,15 +1,14 @@
 #!/bin/bash
-# PMC passes over the attention kernels (separate rocprofv3 runs: counters and traces are never combined).
-#   tools/pmc_attn.sh <outdir>      -> <outdir>/pmc_attn.txt
-out=${1:-gpurun_out/pmc}; mkdir -p $out
-cd /tmp && export TMPDIR=/tmp; cd - > /dev/null
-i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES" \
-           "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU" \
-           "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VALU_TRANS SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT"; do
-  i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set -d $out/p$i -o res -- python3 tools/mb_attn_one.py 2 > $out/p$i.log 2>&1
+# Cycle accounting of the attention kernels at the bench shape: tools/pmc_attn.sh <outdir> fwd|bwd [lib.so]
+out=$1; which=$2; lib=$3; mkdir -p $out
+export TMPDIR=/tmp
+[ -n "$lib" ] && export OSU_DREAMER_HIP_LIB=$PWD/$lib
+export OD_BWD_2STREAM=0
+: > $out/pmc_attn_$which.txt
+for set in "GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU"; do
+  rm -rf $out/p
+  timeout 300 rocprofv3 --pmc $set -d $out/p -o res -- python3 tools/mb_attn_one.py $which 2 > $out/p.log 2>&1
+  python3 tools/rocpd_pmc_dispatch.py $(find $out/p -name "*.db" | head -1) flash 2>&1 | tail -3 >> $out/pmc_attn_$which.txt
 done
-: > $out/pmc_attn.txt
-for db in $(find $out -name "*.db"); do python3 tools/rocpd_pmc.py $db flash >> $out/pmc_attn.txt 2>&1; done
-rocprofv3 -L 2>/dev/null | grep -oE "SQ_[A-Z0-9_]+" | sort -u > $out/sq_counters.txt
+rm -rf $out/p
+cat $out/pmc_attn_$which.txt
