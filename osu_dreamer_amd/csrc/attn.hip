@@ -607,6 +607,16 @@ __device__ __forceinline__ void qk_rope_norm_bwd_dw(f32x4 (&dwacc)[4], float* dw
         }
 }
 
+#ifndef OD_X_BWD_NOSYNC
+#define OD_X_BWD_NOSYNC 0     // timing experiment only (wrong results): 1 = no workgroup barrier in the backward loops, 2 = barrier without the VMEM drain
+#endif
+#if OD_X_BWD_NOSYNC == 1
+#define OD_BWD_LOOP_SYNC() ((void)0)
+#elif OD_X_BWD_NOSYNC == 2
+#define OD_BWD_LOOP_SYNC() od_barrier_raw()
+#else
+#define OD_BWD_LOOP_SYNC() __syncthreads()
+#endif
 // dK, dV: block owns 4 waves x NK*16 keys; loop over 64-query tiles.
 //   S = Q K^T (cols = keys) ; dV^T += dO^T P ; dP = dO V^T ; dS = P*(dP - delta)*scale ; dK^T += Q^T dS
 // LDS per stage: Q, dO row-major (+ Q^T, dO^T for f32); bf16 double-buffers the stage.
@@ -782,7 +792,7 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
             if constexpr (St::TR) lstore_small(smem + (cur ^ 1) * STAGE);
             else lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0));
         }
-        __syncthreads();
+        OD_BWD_LOOP_SYNC();
         if (NSTAGE == 2) cur ^= 1;
     };
     const int nfull = kragged ? 0 : L / 64;
@@ -941,7 +951,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
             }
         if (NSTAGE == 1) __syncthreads();
         if constexpr (!St::TR) { if (kt + 1 < nkt) lstore(smem + (NSTAGE == 2 ? (cur ^ 1) * STAGE : 0)); }
-        __syncthreads();
+        OD_BWD_LOOP_SYNC();
         if (NSTAGE == 2) cur ^= 1;
     };
     const int nfull = L / 64;

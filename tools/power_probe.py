@@ -36,6 +36,6 @@ while not e1.query() and time.time() - t0 < 20:
     samples.append((p.group(1) if p else "?", s.group(1) if s else "?"))
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
-print(f"{which} W4={os.environ.get('OD_NT_W4', '0')} N={N} K={K}: {ms * 1e3:.0f} us/launch, {flops / ms / 1e9:.0f} TF/s; (W, MHz) samples: {samples[1:-1][:12]}")
+print(f"{which} OD_NT_W4={os.environ.get('OD_NT_W4', '1 (default)')} N={N} K={K}: {ms * 1e3:.0f} us/launch, {flops / ms / 1e9:.0f} TF/s; (W, MHz) samples: {samples[1:-1][:12]}")
 if not samples or samples[0][0] == "?":
     print(o[:1500])

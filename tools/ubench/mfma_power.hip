@@ -14,8 +14,15 @@ __global__ __launch_bounds__(256, 1) void k(float* out, int iters) {
     extern __shared__ unsigned char smem[];
     const int lane = threadIdx.x & 63;
     s16x8 fa[8], fb[8];
+    // pseudo-random bf16 operands in [-2, 2): the power an MFMA draws depends on how its operand bits toggle
 #pragma unroll
-    for (int i = 0; i < 8; i++) { fa[i] = (s16x8)((short)(0x3c00 + lane + i)); fb[i] = (s16x8)((short)(0x3c00 + lane * 3 + i)); }
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const unsigned h = (unsigned)(lane * 64 + i * 8 + e) * 2654435761u;
+            fa[i][e] = (short)(0x3f00 + ((h >> 7) & 0xff) + ((h >> 3) & 0x8000));
+            fb[i][e] = (short)(0x3f00 + ((h >> 17) & 0xff) + ((h >> 11) & 0x8000));
+        }
     float s = 0.f;
     if constexpr (SHAPE == 16) {
         f32x4 acc[64];

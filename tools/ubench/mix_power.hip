@@ -1,6 +1,7 @@
 // Sustained rate at the power limit of a 64-MFMA loop with one class of filler added: ./mix_power MODE [seconds]
 //   0 none | 1 +32 v_exp_f32 | 2 +32 v_cvt_pk_bf16_f32 | 3 +16 v_pk_mul_f32 | 4 +16 ds_read_b128 | 5 +32 ds_read_b64_tr_b16 | 6 = 1+2+3 | 7 = 1+2+3+4+5
-//   8 +32 v_exp_f16 | 9 +32 v_fma_f32
+//   8 +32 v_exp_f16 | 9 +32 v_fma_f32 | 10 the attention-backward mix without packed math: 32 exp, 32 v_mul, 32 cvt, 12 ds_read_b128, 16 tr reads
+//   11 = 10 with two fillers behind every MFMA that has any (bunched)
 // One wave per SIMD, fillers between MFMAs (one per two MFMAs), random-ish operand data.
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -42,8 +43,16 @@ __global__ __launch_bounds__(256, 1) void k(float* out, int iters) {
             if (MUL && (n & 3) == 2) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pm[(n >> 2) & 3]) : "v"(pm[((n >> 2) + 1) & 3]));
             if (LDS && (n & 3) == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lr) : "v"(laddr), "i"((n >> 2) * 1024));
             if (TRR && (n & 1) == 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(tr) : "v"(laddr), "i"((n >> 1) * 1024));
+            if (MODE == 10 || MODE == 11) {
+                // 124 fillers over 64 MFMAs: ~2 per MFMA
+                if ((n & 1) == 0) asm volatile("v_exp_f32_e32 %0, %0" : "+v"(e[(n >> 1) & 7]));
+                if ((n & 1) == 1) asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(e[(n >> 1) & 7]) : "v"(e[((n >> 1) + 1) & 7]));
+                if ((n & 1) == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(cv[(n >> 1) & 3]) : "v"(e[(n >> 1) & 7]), "v"(e[((n >> 1) + 1) & 7]));
+                if (n % 5 == 1 && n / 5 < 12) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lr) : "v"(laddr), "i"((n / 5) * 1024));
+                if ((n & 3) == 3) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(tr) : "v"(laddr), "i"((n >> 2) * 1024));
+            }
         }
-        if (LDS || TRR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (LDS || TRR || MODE == 10 || MODE == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float s = 0.f;
@@ -77,7 +86,7 @@ int main(int argc, char** argv) {
     switch (mode) {
         case 0: run<0>(out, secs); break; case 1: run<1>(out, secs); break; case 2: run<2>(out, secs); break; case 3: run<3>(out, secs); break;
         case 4: run<4>(out, secs); break; case 5: run<5>(out, secs); break; case 6: run<6>(out, secs); break; case 7: run<7>(out, secs); break;
-        case 8: run<8>(out, secs); break; case 9: run<9>(out, secs); break;
+        case 8: run<8>(out, secs); break; case 9: run<9>(out, secs); break; case 10: run<10>(out, secs); break;
     }
     return 0;
 }
