@@ -122,6 +122,22 @@ def load_pmc(B, L):
                         "note": "no profiles/r*_traffic.json was taken on this build (or at this batch x frames): counters not quoted"}
 
 
+def load_power_context():
+    """The dense bf16 rate this board SUSTAINS under its power cap: bare v_mfma_f32_16x16x32_bf16 on pseudo-random operands, one wave per
+    SIMD, nothing else in the loop (tools/ubench/mfma_power.hip; committed as profiles/r*_mfma_power.txt, measured on some box of the
+    pool - boxes differ by +-5 %).  Context for `frac`, whose `peak` stays the guide's 2500."""
+    import glob, re
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_mfma_power.txt")), reverse=True):
+        try:
+            m = re.search(r"shape 16:.*?:\s*(\d+) TF/s", open(path).read())
+        except Exception:
+            continue
+        if m:
+            return {"bare_mfma_16x16x32_sustained_tflops": int(m.group(1)), "source": os.path.relpath(path, REPO),
+                    "note": "power-throttled (1400 W cap); not measured in this run"}
+    return None
+
+
 def load_sampler_parity():
     """tests/test_sampler50.py's record of the 50-step sampler against the REFERENCE's own run (tests/golden/sample50_full_d8_b4_l1115.npz),
     committed as profiles/r*_sampler_parity.json; quoted only when it was measured on this build."""
@@ -177,7 +193,8 @@ def roofline_of_dominant_kernel(tr, B, L):
                                        "ms_per_launch": round(t_fwd * 1e3, 3)},
                  # per kernel class over one step, from the same PMC record as `traffic` (null when that record is not of this build):
                  # HBM fraction of 8 TB/s for the memory-bound classes, MFMA-pipe busy fraction for the matrix classes
-                 "pmc_classes": classes},
+                 "pmc_classes": classes,
+                 "power_limit": load_power_context()},
     }
 
 

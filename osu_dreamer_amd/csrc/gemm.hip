@@ -571,8 +571,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
     const int ld = isw ? ldw : lda, lim = isw ? N : M;
     auto srd_of = [&](int m0_, int n0_, bool valid) {                       // this wave's operand rows of the tile at (m0_, n0_)
         const int r0 = isw ? n0_ : m0_;
-        const long avail = (long)(lim - r0 - 1) * ld + K;                   // elements to the end of the last valid row
-        return od_make_srd((isw ? W : A) + (size_t)r0 * ld, valid ? (unsigned)((avail > 0 ? avail : 0) * 2) : 0u);
+        const int rows = lim - r0 < 256 ? lim - r0 : 256;                   // the descriptor covers this tile's rows only: its 32-bit length
+        const long avail = (long)(rows - 1) * ld + K;                       // never sees the size of the whole matrix; it ends with the last valid row
+        return od_make_srd((isw ? W : A) + (size_t)r0 * ld, valid && rows > 0 ? (unsigned)(avail * 2) : 0u);
     };
     od_srd_t srd_cur = srd_of(m0, n0, true), srd_nxt = srd_cur, srd = srd_cur;
     const int prow = lane >> 3;

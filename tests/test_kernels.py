@@ -63,6 +63,11 @@ def test_gemm_nt_large_m(M, N, K):
     ops.gemm_nt(A, W, None, C, accumulate=True)
     ref2 = ref - b + C0.float()
     assert float((C.float() - ref2).norm() / ref2.norm()) < TOL[bf]
+    # no bias (the 4-wave kernel's accumulators then start at zero), into a column range of a wider tensor (ldc > N)
+    wide = torch.full((M, N + 64), 7.0, dtype=bf, device=dev)
+    ops.gemm_nt(A, W, None, wide[:, :N])
+    assert float((wide[:, :N].float() - (ref - b)).norm() / (ref - b).norm()) < TOL[bf]
+    assert bool((wide[:, N:] == 7.0).all())                                               # nothing written past column N
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
