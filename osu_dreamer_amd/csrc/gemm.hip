@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
     using T = bf16_t;
     constexpr int TM = 256, TN = 256, STG = 65536;       // stage: A 32 KiB (256 rows x 128 B) then W 32 KiB
     OD_DYN_SMEM(smem);
-    // PERSISTENT: one workgroup per CU (grid = 256) walks output tiles v = 0, 1, ... — the tile a grid of gridDim.x * (v + 1) blocks would
+    // PERSISTENT: one workgroup per CU (grid = od_num_cus(), 256 on MI355X) walks output tiles v = 0, 1, ... — the tile a grid of gridDim.x * (v + 1) blocks would
     // give block blockIdx.x + gridDim.x * v under tile_of_block's XCD-aware order — and the operand pipeline runs across the tile
     // boundary: the last two K tiles of an output tile fetch the first two of the next one, whose first fragments are in registers when the
     // epilogue starts.  A cold start (fetch latency, ~2 us) and a drained pipeline per output tile cost the non-persistent form ~8 % at
@@ -1076,10 +1076,12 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
             static const int w4 = od_env_int("OD_NT_W4", 1);
             static const int w4_min_k = od_env_int("OD_NT_W4_MIN_K", 0);
             if (w4 && epi != OD_EPI_QKROPE && !accumulate && K >= w4_min_k && K % 128 == 0) {
+                int pgrid = od_num_cus() & ~7;                 // persistent: one workgroup per CU, a multiple of 8 (block b runs on XCD b % 8)
+                pgrid = pgrid < 8 ? 8 : pgrid;
                 if (epi == OD_EPI_SILU)
-                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_SILU>), dim3(grid2 < 256 ? grid2 : 256), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
+                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_SILU>), dim3(grid2 < pgrid ? grid2 : pgrid), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
                 else
-                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_NONE>), dim3(grid2 < 256 ? grid2 : 256), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
+                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_NONE>), dim3(grid2 < pgrid ? grid2 : pgrid), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
                 OD_CHECK_LAUNCH();
                 return 0;
             }

@@ -8,3 +8,20 @@ inline int od_env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+
+// Compute units of the CURRENT device, for the persistent kernels' grids (one workgroup per CU); cached per device id.  The emulator has none:
+// it runs the persistent grid at 16 workgroups (two per "XCD" of the tile order).
+#if defined(OD_EMU)
+inline int od_num_cus() { return 16; }
+#else
+inline int od_num_cus() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cache[dev]) {
+        int n = 0;
+        cache[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cache[dev];
+}
+#endif

@@ -302,7 +302,8 @@ __device__ __forceinline__ void od_buffer_lds16_at(od_srd_t r, unsigned voff, un
     od_buffer_lds16(r, voff, soff, emu::dyn_smem() + (long)(int)lds_addr);     // signed: a static __shared__ array may lie below the dynamic one
 }
 __device__ __forceinline__ void od_buffer_lds16_at_nt(od_srd_t r, unsigned voff, unsigned soff, unsigned lds_addr) { od_buffer_lds16_at(r, voff, soff, lds_addr); }
-__device__ __forceinline__ unsigned& od_emu_m0() { static thread_local unsigned m0 = 0; return m0; }
+// M0 is a per-wave register: the emulator's fibers of one workgroup share an OS thread, so the stand-in is indexed by the wave
+__device__ __forceinline__ unsigned& od_emu_m0() { static thread_local unsigned m0[32] = {0}; return m0[emu::wave_id() & 31]; }
 __device__ __forceinline__ void od_dma_set_dst(unsigned lds_addr) { od_emu_m0() = lds_addr; }
 __device__ __forceinline__ void od_buffer_lds16_m0(od_srd_t r, unsigned voff, unsigned soff) { od_buffer_lds16_at(r, voff, soff, od_emu_m0()); }
 // one dword per lane: lane i's 4 bytes land at lds_addr + 4*i (zero past the end of the buffer)

@@ -25,7 +25,9 @@ def mk(shape, g, dev, dtype=torch.float32, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (128, 128, 64), (77, 24, 16), (300, 384, 192), (2100, 520, 128)])
+# (2100, 520, 128) and (1500, 264, 256): on the emulator build (large-M threshold 256 rows, 16 "CUs") the persistent 4-wave kernel walks 2-3 output
+# tiles per workgroup with ragged row / column tiles, its operand pipeline crossing the tile boundary (K = 256: also inside a tile)
+@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (128, 128, 64), (77, 24, 16), (300, 384, 192), (2100, 520, 128), (1500, 264, 256)])
 def test_gemm_nt(dev, dtype, M, N, K):
     g = torch.Generator().manual_seed(1)
     A, W, b = mk((M, K), g, dev, dtype), mk((N, K), g, dev, dtype, 0.2), mk((N,), g, dev)
