@@ -104,18 +104,20 @@ __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d
 __device__ __forceinline__ void st4(f32x3_t* p, float a, float b, float c, float d) { st4((float*)p, a, b, c, d); }
 
 // ======================================================================== forward
-// block: 4 waves x 32 query rows; loop over 64-key tiles, double-buffered in LDS.
+// block: 4 waves x NQT 16-query tiles (32 or 16 query rows per wave); loop over 64-key tiles, double-buffered in LDS.
+// NQT = 1 halves a wave's work and its registers: at sampler sizes (B*H*L/32 = 2240 waves of work against 2048 wave slots at two waves per
+// SIMD) the 32-query form runs two rounds for 1.09 rounds of work.
 // PRE: q arrives multiplied by scale*log2(e) (od_qk_norm_rope's q_scale), so q.k is already the base-2 exponent and
 // the per-element multiply disappears from the loop.
-template <class T, int HD, int NW, bool PRE>
-__global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+template <class T, int HD, int NW, bool PRE, int NQT = 2>
+__global__ __launch_bounds__(64 * NW, (NW >= 6 || NQT == 1 ? 3 : 2)) void flash_fwd_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                            const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
                                                            float* __restrict__ lse, int B, int H, int L, float scale) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32;   // 32-deep slabs over the head dim
     constexpr int ND = HD / 16;   // 16-row tiles over the head dim
     OD_DYN_SMEM(smem);   // 2 stages x (K row-major, V row-major [bf16] or V^T [f32])
-    constexpr int QB = NW * 32;
+    constexpr int QB = NW * 16 * NQT;
     const int nqt = (L + QB - 1) / QB;
     int qt, bh;
     if (!attn_block_coords(nqt, B * H, qt, bh)) return;
@@ -124,17 +126,17 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
     const T* qb = q + (size_t)b * L * ldq + h * HD;
     const T* kb = k + (size_t)b * L * ldk + h * HD;
     const T* vb = v + (size_t)b * L * ldv + h * HD;
-    const int q0 = qt * QB + wave * 32;
+    const int q0 = qt * QB + wave * 16 * NQT;
     const float c = PRE ? 1.f : scale * LOG2E;
 
-    od_frag<T> fq[2][NS];
+    od_frag<T> fq[NQT][NS];
 #pragma unroll
-    for (int qi = 0; qi < 2; qi++) {
+    for (int qi = 0; qi < NQT; qi++) {
         int row = q0 + qi * 16 + x; row = row < L ? row : L - 1;
 #pragma unroll
         for (int s = 0; s < NS; s++) od_frag_load(fq[qi][s], qb + (size_t)row * ldq + s * 32 + g * 8);
     }
-    f32x4 oacc[2][ND];
+    f32x4 oacc[NQT][ND];
     // Softmax against a LAZY reference (VALU diet: the loop is bound by the vector ALU, not the MFMA — 32 exps at
     // quarter rate per lane per tile already cost as many cycles as the 32 MFMAs).  mref[qi] is a per-query
     // reference score, set to the row max of the first key tile and raised only when a later tile exceeds it by
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
     // takes one packed multiply per pair — no fma, no cross-lane max, no rescale of O on the common path.
     // p <= 2^OD_FWD_SLACK keeps fp32 sums and bf16 P far from overflow; the result is the same softmax
     // (shift invariance), lse = mref * scale + ln(l).
-    float mref[2], lrun[2];
+    float mref[NQT], lrun[NQT];
 #pragma unroll
-    for (int qi = 0; qi < 2; qi++) {
+    for (int qi = 0; qi < NQT; qi++) {
         mref[qi] = 0.f; lrun[qi] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < ND; dt++) oacc[qi][dt] = (f32x4)(0.f);
@@ -179,14 +181,14 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
         }
 
         // S^T tiles: rows = keys (4 tiles of 16), cols = queries; accumulators start at -mref
-        f32x4 e[2][4];
+        f32x4 e[NQT][4];
 #pragma unroll
         for (int t4 = 0; t4 < 4; t4++) {
             od_frag<T> fk[NS];
 #pragma unroll
             for (int s = 0; s < NS; s++) frag_contig<St::ROWB>(fk[s], tK, t4 * 16 + x, s * 32 + g * 8);
 #pragma unroll
-            for (int qi = 0; qi < 2; qi++) {
+            for (int qi = 0; qi < NQT; qi++) {
                 f32x4 a = (f32x4)(-mref[qi]);
 #pragma unroll
                 for (int s = 0; s < NS; s++) a = od_mma(fk[s], fq[qi][s], a);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
         const int kbase = kt * 64;
         if constexpr (MASKED) {    // ragged last tile only: mask keys >= L
 #pragma unroll
-            for (int qi = 0; qi < 2; qi++)
+            for (int qi = 0; qi < NQT; qi++)
 #pragma unroll
                 for (int t4 = 0; t4 < 4; t4++)
 #pragma unroll
@@ -204,18 +206,18 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
                         if (kbase + t4 * 16 + 4 * g + r >= L) e[qi][t4][r] = NEG_BIG;
         }
         // lane-local maxima (lane owns query column x, keys 16*t4 + 4g + r)
-        float mx[2];
+        float mx[NQT];
 #pragma unroll
-        for (int qi = 0; qi < 2; qi++) {
+        for (int qi = 0; qi < NQT; qi++) {
             mx[qi] = fmaxf(fmaxf(e[qi][0][0], e[qi][0][1]), fmaxf(e[qi][0][2], e[qi][0][3]));
 #pragma unroll
             for (int t4 = 1; t4 < 4; t4++)
                 mx[qi] = fmaxf(mx[qi], fmaxf(fmaxf(e[qi][t4][0], e[qi][t4][1]), fmaxf(e[qi][t4][2], e[qi][t4][3])));
         }
         // rare path (always on the first tile): move the reference.  Wave-uniform branch.
-        if (FIRST || __any(fmaxf(mx[0], mx[1]) > OD_FWD_SLACK)) {
+        if (FIRST || __any(fmaxf(mx[0], mx[NQT - 1]) > OD_FWD_SLACK)) {
 #pragma unroll
-            for (int qi = 0; qi < 2; qi++) {
+            for (int qi = 0; qi < NQT; qi++) {
                 float m = mx[qi];
                 m = fmaxf(m, __shfl_xor(m, 16));
                 m = fmaxf(m, __shfl_xor(m, 32));
@@ -231,9 +233,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
                 for (int t4 = 0; t4 < 4; t4++) e[qi][t4] -= d;
             }
         }
-        od_frag<T> fp[2][2];
+        od_frag<T> fp[NQT][2];
 #pragma unroll
-        for (int qi = 0; qi < 2; qi++) {
+        for (int qi = 0; qi < NQT; qi++) {
             f32x4 ps = (f32x4)(0.f);
 #pragma unroll
             for (int t4 = 0; t4 < 4; t4++) {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
                 od_frag<T> fv;
                 frag_cols<St::ROWB, St::TROWB>(fv, tV, tV, dt * 16, x, u, g);
 #pragma unroll
-                for (int qi = 0; qi < 2; qi++) oacc[qi][dt] = od_mma(fv, fp[qi][u], oacc[qi][dt]);
+                for (int qi = 0; qi < NQT; qi++) oacc[qi][dt] = od_mma(fv, fp[qi][u], oacc[qi][dt]);
             }
         if constexpr (!St::TR) { if (kt + 1 < nkt) lstore(smem + ((kt + 1) & 1) * 2 * St::BYTES); }
         __syncthreads();
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_fwd_kernel(c
     for (int kt = 1; kt < nfull; kt++) tile(kt, std::false_type{}, std::false_type{});
     if (nfull > 0 && nfull < nkt) tile(nfull, std::true_type{}, std::false_type{});
 #pragma unroll
-    for (int qi = 0; qi < 2; qi++) {
+    for (int qi = 0; qi < NQT; qi++) {
         float l = lrun[qi];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
@@ -1165,6 +1167,11 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dq32_kernel(const bf16_t
 #ifndef OD_ATTN_NW
 #define OD_ATTN_NW 4      // waves per workgroup of the bf16 forward / dQ kernels.  6 (K/V streamed once per 192 queries) measured 0.71x: a 6-wave group lands 2,2,1,1 on the SIMDs and a second group no longer fits at 3 waves/SIMD
 #endif
+#ifndef OD_FWD_NQT1_BELOW
+#define OD_FWD_NQT1_BELOW 2048  // fp32 forward, head_dim 64: 16 queries per wave when the 32-query grid has fewer workgroups than this (0 = never).  At the sampler's size
+                                // (576 workgroups = 1.09 rounds of the chip run as two) the fp32 call goes 293.5 -> 287.3 ms; the fp32-bf16x3 product, whose hi / lo fragment
+                                // split is amortised over half the MFMAs then, 155.5 -> 170.8 ms: fp32 only
+#endif
 #ifndef OD_FWD32
 #define OD_FWD32 1        // bf16, head_dim 64: the 32x32x16 kernel (0 = the 16x16x32 kernel, kept for A/B and for hd 32 / fp32)
 #endif
@@ -1192,6 +1199,16 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
         return 0;
     }
     constexpr int NW = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
+    // fp32: 16 queries per wave when the 32-query grid is only a few rounds of the chip (sampler sizes): half-size waves quantise better
+    static const int nqt1_below = od_env_int("OD_FWD_NQT1_BELOW", OD_FWD_NQT1_BELOW);       // workgroups of the 32-query form
+    const int blocks2 = ((L + NW * 32 - 1) / (NW * 32)) * B * H;
+    if (std::is_same<T, float>::value && HD == 64 && blocks2 < nqt1_below) {
+        const int grid = attn_grid((L + NW * 16 - 1) / (NW * 16), B * H);
+        OD_LAUNCH_DYN((flash_fwd_kernel<T, HD, NW, PRE, 1>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
+                  (T*)o, ldo, lse, B, H, L, scale);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     const int grid = attn_grid((L + NW * 32 - 1) / (NW * 32), B * H);
     OD_LAUNCH_DYN((flash_fwd_kernel<T, HD, NW, PRE>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv,
               (T*)o, ldo, lse, B, H, L, scale);
