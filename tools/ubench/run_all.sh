@@ -1,6 +1,6 @@
 #!/bin/bash
 # All micro-benchmarks behind the round-3 GEMM / attention decisions, one call:  tools/ubench/run_all.sh <outdir>
-# (binaries are built in-tree beforehand: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/X tools/ubench/X.hip)
+# (binaries are built in-tree beforehand: tools/ubench/build.sh)
 out=${1:-gpurun_out/ubench}; mkdir -p $out
 smi() { /opt/rocm/bin/rocm-smi -P -c 2>/dev/null | grep -E "Power|sclk" | sed "s/.*: //" | tr "\n" " "; }
 ./tools/ubench/barrier_cost > $out/barrier_cost.txt 2>&1
