@@ -90,10 +90,12 @@ def time_kernel(fn, iters=3):
 BWD_PASSES_ALGORITHMIC = 5     # S = QK^T recompute, dP = dO V^T, dV = P^T dO, dK = dS^T Q, dQ = dS K  (backward = 2x forward + recompute)
 
 
-def bwd_passes_executed():
-    """MFMA passes od_flash_attn_bwd actually issues (5 for the single-kernel backward; 7 when dK/dV and dQ are separate
-    kernels that each recompute S and dP)."""
+def bwd_passes_executed(eng=None):
+    """MFMA passes the attention backward of the plan actually issues (5 for the single-kernel backward od_flash_attn_bwd_fused;
+    7 when dK/dV and dQ are separate kernels that each recompute S and dP)."""
     from osu_dreamer_amd import _lib
+    if eng is not None:
+        return eng.attn_bwd_passes()
     return int(_lib.lib().cdll.od_flash_attn_bwd_passes())
 
 
@@ -167,21 +169,21 @@ def roofline_of_dominant_kernel(tr, B, L):
     dy, dqkv, delta = t["d.y"], t["d.qkv"], t["d.delta"]
     scale = 1 / math.sqrt(hd)
 
-    fused = eng.fused_rope_bwd()
+    fused = eng.fused_attn_bwd()
 
-    def bwd():       # exactly as the step launches it: delta, then dK/dV and dQ side by side (od_flash_attn_bwd_aux)
+    def bwd():       # exactly as the step launches it
         eng.attn_bwd_launch(i, dy, delta, dqkv, core_only=True)
 
     def fwd():
         ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, H, L, hd, scale, q_prescaled=True)
     unit = 2.0 * B * H * L * L * hd                 # one L x L x hd MFMA pass over all heads
     t_bwd, t_fwd = time_kernel(bwd), time_kernel(fwd)
-    executed = bwd_passes_executed()
+    executed = bwd_passes_executed(eng)
     traffic, classes, traffic_src = load_pmc(B, L)
     ach_bwd = BWD_PASSES_ALGORITHMIC * unit / t_bwd / 1e12
     ach_fwd = 2 * unit / t_fwd / 1e12
     return {
-        "bound": "mfma", "kernel": ("od_flash_attn_bwd_qkrope (attention backward of one layer, q/k norm + RoPE backward in its epilogues)" if fused else
+        "bound": "mfma", "kernel": ("od_flash_attn_bwd_fused (attention backward of one layer: start values, then ONE persistent kernel — S, dP, dV, dK, dQ; dQ summed over key blocks by the L2 chain)" if fused else
                                    "od_flash_attn_bwd (attention backward of one layer: delta, then dK/dV and dQ on two streams)"),
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -450,7 +452,7 @@ def main():
         f_fwd = flops_forward(frames, L)
         # executed MFMA work: forward + 2x GEMM backward + attention backward as its executed passes (vs 2 forward)
         attn_fwd = frames * 32_768 * L
-        executed = f_fwd + 2 * (f_fwd - attn_fwd) + bwd_passes_executed() / 2 * attn_fwd
+        executed = f_fwd + 2 * (f_fwd - attn_fwd) + bwd_passes_executed(tr.diffusion.engine) / 2 * attn_fwd
         named = {(32, 8192): "BASELINE.json configs[1]", (8, 32768): "BASELINE.json configs[4] shape; attention in bf16 MFMA where configs[4] says fp16 (same MFMA rate, no loss scaling)",
                  (2, 4096): "BASELINE.json configs[0] shape, on the GPU"}.get((B, L), "custom --batch/--frames")
         if world > 1 and (B, L) == (32, 8192):

@@ -50,16 +50,6 @@ const char* od_error_string(int code);
  *           model.py:45 (proj_audio), and their autograd backward-data. */
 int od_gemm_nt(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
                int M, int N, int K, int epilogue, int accumulate, void* stream);
-/* The same product through the vendor library (hipBLASLt), for PLAIN GEMMs only — no epilogue but the bias, no accumulate, bf16.  At
- * M = 262,144 the library's hand-scheduled assembly kernel is 20-27 % faster than gemm_nt_big_kernel on the four long-K, N = 512 shapes of a
- * layer (profiles/r03_gemm_vs_vendor.txt); the host routes exactly those there.  od_vendor_gemm_create binds the library at run time
- * (dlopen(libpath), "libhipblaslt.so" when NULL / empty) and returns a handle object the caller owns; `workspace` is caller-owned device
- * memory the library may use (its size is part of the plan: keep it constant).  Any failure — library missing, shape unsupported — is
- * OD_ERR_UNSUPPORTED, and the caller uses od_gemm_nt.  Not for hipGraph capture (training path only). */
-int od_vendor_gemm_create(void** vg_out, const char* libpath);
-int od_vendor_gemm_destroy(void* vg);
-int od_gemm_nt_vendor(void* vg, int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
-                      int M, int N, int K, void* workspace, long workspace_bytes, void* stream);
 /* the qkv projection with the q/k RMSNorm + RoPE applied in its epilogue (no-grad forward / sampler: no separate
  * od_qk_norm_rope pass): C[:, :2*H*hd] = rope(rms_norm(A W^T + bias) * w), C[:, 2*H*hd:] = A W^T + bias.
  * hd in {32, 64}; the pre-norm values are rounded to dtype first, so the result equals od_gemm_nt + od_qk_norm_rope.
@@ -163,15 +153,21 @@ int od_attn_aux_destroy(void* aux);
 int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o,
                           int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk,
                           int lddk, void* dv, int lddv, int B, int H, int L, int hd, float scale, int q_prescaled, void* aux, void* stream);
-/* od_flash_attn_bwd and od_qk_norm_rope_bwd in one: q, k are the normed + rotated operands, qkv the PRE-norm projection [M, 3*H*hd]
- * (q | k | v column blocks; v is read from it), dqkv [M, 3*H*hd] receives the gradient of that projection (the backward of the norm + RoPE
- * runs on the dQ / dK accumulators in the attention kernels' epilogues: dq and dk never exist in memory), dwq / dwk [hd] += the norm weight
- * gradients.  bf16, head_dim 64 only (OD_ERR_UNSUPPORTED otherwise: call the two entry points above).
- * replaces: autograd of attn.py:74-82. */
-int od_flash_attn_bwd_qkrope(int dtype, const void* q, int ldq, const void* k, int ldk, const void* qkv, int ldqkv, const void* o,
-                             int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dqkv, int lddqkv,
-                             const float* wq, const float* wk, const float* table, float* dwq, float* dwk, int B, int H, int L,
-                             int hd, float scale, float eps, float q_scale, int q_prescaled, void* stream);
+/* The same gradients from ONE kernel that executes the 5 algorithmic MFMA passes (od_flash_attn_bwd executes 7: its dQ kernel recomputes S and dP).
+ * bf16, head_dim 64 only (OD_ERR_UNSUPPORTED otherwise: call od_flash_attn_bwd).  Each workgroup owns 192 keys; its share of every 64-query
+ * dQ tile is added to a running fp32 tile that travels key block -> key block through the XCD's L2 in a fixed order (deterministic, no
+ * atomics on data), and the last key block writes dq.  `ws` is caller-owned device memory of od_flash_attn_bwd_fused_ws_bytes(...) bytes whose first
+ * *zero_out bytes are zero before the first call (every call leaves them zero); one workspace serves any number of calls on one stream.
+ * od_flash_attn_bwd_fused_status copies the workspace's sticky error word to the host (0 = every launch processed all of its jobs; it
+ * synchronises the device: a test / debug aid).  replaces: autograd of attn.py:82. */
+int od_flash_attn_bwd_fused_ws_bytes(int B, int H, int L, long* total_out, long* zero_out);
+int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
+                            const void* dout, int lddo, const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
+                            int B, int H, int L, int hd, float scale, int q_prescaled, void* ws, long ws_bytes, void* stream);
+int od_flash_attn_bwd_fused_status(const void* ws, int* err_out);
+int od_flash_attn_bwd_fused_passes(void);
+/* profiling builds (-DFB_PROF=1) only: 16 cycle counters of the workspace, copied out and cleared; zeros otherwise. */
+int od_flash_attn_bwd_fused_prof(void* ws, long* out16);
 /* L x L x hd MFMA passes one od_flash_attn_bwd call issues for bf16 (the algorithmic minimum with the score recompute is 5);
  * bench.py reports it next to the algorithmic roofline figure. */
 int od_flash_attn_bwd_passes(void);

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libosudreamer_hip.so
-SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip style.hip latent.hip comm.hip vendor_gemm.hip"
+SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip attn_bwd_fused.hip style.hip latent.hip comm.hip"
 OBJS=""
 PIDS=""
 mkdir -p build
@@ -20,7 +20,7 @@ for s in $SRCS; do
     # attn.hip has no NaN/Inf by construction (finite -1e30 mask): lets hipcc drop the canonicalising v_max
     # -fno-slp-vectorize: keeps the softmax row sums as scalar v_add_f32; SLP packs them into v_pk_add_f32, which costs more
     # than the two adds it replaces beside MFMAs (fwd 8.85 -> 8.05 ms in one A/B run, profiles/r02c_ab_attn.txt)
-    [ "$s" = "attn.hip" ] && extra="-ffinite-math-only -fno-slp-vectorize"
+    case "$s" in attn*.hip) extra="-ffinite-math-only -fno-slp-vectorize";; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c "$s" -o "$o" ${OD_HIPCC_FLAGS} &
     PIDS="$PIDS $!"
   fi

@@ -534,16 +534,100 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
     }
 }
 
+// ---- backward of the q / k RMSNorm + RoPE (attn.py:77-81) applied to the dQ / dK accumulators in the attention kernels' epilogues
+// (round 3; bf16, head_dim 64).  The separate od_qk_norm_rope_bwd pass read dq, dk (M x 2*H*hd) and the pre-norm q, k and wrote the
+// gradient of the qkv projection: 3.2 GB per layer at 4.8 TB/s = 0.67 ms.  In the epilogue the gradient row is already in registers
+// (fp32, not yet rounded), a lane holds features 16 dt + 4 g + r of its row — the rotary partner d +- 32 is accumulator tile dt ^ 2 of
+// the same lane, the row's sums over 64 features are 16 in-lane terms and two shuffles — and only the pre-norm row is read.
+struct RopeBwdEpi {
+    const bf16_t* pre; int ldpre;      // pre-norm q (resp. k) columns of the qkv projection: row m, head h at pre[m * ldpre + h * 64]
+    const float* w;                    // nn.RMSNorm weight [64]
+    const float* table;                // (cos, sin) [L][32][2]
+    float* dw;                         // += gradient of w
+    float eps, gs;                     // gs: the factor the forward multiplied its output by (q: q_scale, k: 1)
+};
+// a[dt][r]: gradient wrt the normed + rotated (+ scaled) row, feature 16 dt + 4 g + r.  Stores the gradient wrt the pre-norm row to `out`
+// (if valid) and adds this row's share of the weight gradient to dwacc.  Must be called by all 64 lanes (shuffles).
+__device__ __forceinline__ void qk_rope_norm_bwd_row(const f32x4 (&a)[4], const RopeBwdEpi& rb, long m, int l, int h, int g, bool valid,
+                                                     bf16_t* out, f32x4 (&dwacc)[4]) {
+    const bf16_t* xr = rb.pre + m * rb.ldpre + h * 64 + 4 * g;
+    float xv[4][4], ss = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        const u32x2 raw = *(const u32x2*)(xr + dt * 16);
+        union { uint32_t u; float f; } c0, c1, c2, c3;
+        c0.u = raw[0] << 16; c1.u = raw[0] & 0xffff0000u; c2.u = raw[1] << 16; c3.u = raw[1] & 0xffff0000u;
+        xv[dt][0] = c0.f; xv[dt][1] = c1.f; xv[dt][2] = c2.f; xv[dt][3] = c3.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) ss += xv[dt][r] * xv[dt][r];
+    }
+    ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+    const float inv = rsqrtf(ss * (1.f / 64.f) + rb.eps);
+    float cs[2][4], sn[2][4];
+#pragma unroll
+    for (int dl = 0; dl < 2; dl++) {
+        float t[8];
+        od_ld8(rb.table + ((size_t)l * 32 + dl * 16 + 4 * g) * 2, t);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { cs[dl][r] = t[2 * r]; sn[dl][r] = t[2 * r + 1]; }
+    }
+    float dy[4][4], xh[4][4], dot = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        const f32x4 wv = *(const f32x4*)(rb.w + dt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float d = valid ? a[dt][r] * rb.gs : 0.f, dp = valid ? a[dt ^ 2][r] * rb.gs : 0.f;
+            const float u = d * cs[dt & 1][r] + dp * (dt < 2 ? sn[dt & 1][r] : -sn[dt & 1][r]);      // un-rotation
+            xh[dt][r] = xv[dt][r] * inv;
+            dwacc[dt][r] += u * xh[dt][r];
+            dy[dt][r] = u * wv[r];
+            dot += dy[dt][r] * xh[dt][r];
+        }
+    }
+    dot += __shfl_xor(dot, 16); dot += __shfl_xor(dot, 32);
+    dot *= (1.f / 64.f);
+    if (valid) {
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+            st4(out + dt * 16 + 4 * g, inv * (dy[dt][0] - xh[dt][0] * dot), inv * (dy[dt][1] - xh[dt][1] * dot),
+                inv * (dy[dt][2] - xh[dt][2] * dot), inv * (dy[dt][3] - xh[dt][3] * dot));
+    }
+}
+// the wave's weight-gradient partials: sum over the 16 rows (lanes x) of each feature group g, 64 atomics per wave
+__device__ __forceinline__ void qk_rope_norm_bwd_dw(f32x4 (&dwacc)[4], float* dw, int x, int g) {
+#if defined(OD_RB_NO_DW)
+    return;      // timing experiment only: what the epilogue costs without its atomics
+#endif
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = dwacc[dt][r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (x == 0) atomicAdd(dw + dt * 16 + 4 * g + r, v);
+        }
+}
+
+#ifndef OD_X_BWD_NOSYNC
+#define OD_X_BWD_NOSYNC 0     // timing experiment only (wrong results): 1 = no workgroup barrier in the backward loops, 2 = barrier without the VMEM drain
+#endif
+#if OD_X_BWD_NOSYNC == 1
+#define OD_BWD_LOOP_SYNC() ((void)0)
+#elif OD_X_BWD_NOSYNC == 2
+#define OD_BWD_LOOP_SYNC() od_barrier_raw()
+#else
 #define OD_BWD_LOOP_SYNC() __syncthreads()
+#endif
 // dK, dV: block owns 4 waves x NK*16 keys; loop over 64-query tiles.
 //   S = Q K^T (cols = keys) ; dV^T += dO^T P ; dP = dO V^T ; dS = P*(dP - delta)*scale ; dK^T += Q^T dS
 // LDS per stage: Q, dO row-major (+ Q^T, dO^T for f32); bf16 double-buffers the stage.
-template <class T, int HD, int NK, int NWK, bool PRE>
+template <class T, int HD, int NK, int NWK, bool PRE, bool RB = false>
 __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                                const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                T* __restrict__ dk, int lddk, T* __restrict__ dv, int lddv,
-                                                               int B, int H, int L, float scale) {
+                                                               int B, int H, int L, float scale, RopeBwdEpi rb) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32, ND = HD / 16, KB = NWK * NK * 16;
     static_assert(NWK == 4 || St::TR, "the register-staged (f32) path assumes 256 threads");
@@ -651,11 +735,30 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
             const f32x4 l4 = *(const f32x4*)(s_lse + t4 * 16 + 4 * g);
             const f32x4 d4 = *(const f32x4*)(s_delta + t4 * 16 + 4 * g);
 
+#ifndef OD_DKV_CHAINS
+#define OD_DKV_CHAINS 0     // 1: the score / dP MFMA chains of the NK key tiles are issued interleaved (a dependent MFMA sits NK * 2 MFMAs behind its
+                            // producer instead of right behind it, no s_nop in front of the exponentials).  Measured SLOWER with two waves per SIMD
+                            // (24.5 vs 24.1 ms per layer, three rounds): the other wave already fills those stalls, and the burst of 12 MFMAs then
+                            // 30 VALU instructions gives it less to interleave with.
+#endif
+            f32x4 sa_[NK], pa_[NK];
+            if constexpr (OD_DKV_CHAINS) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+#pragma unroll
+                    for (int ki = 0; ki < NK; ki++) sa_[ki] = od_mma(fqr[s], fk[ki][s], s == 0 ? l4 : sa_[ki]);
+#pragma unroll
+                    for (int ki = 0; ki < NK; ki++) pa_[ki] = od_mma(fdo[s], fv[ki][s], s == 0 ? d4 : pa_[ki]);
+                }
+            }
 #pragma unroll
             for (int ki = 0; ki < NK; ki++) {
                 f32x4 sa = l4, pa = d4;
+                if constexpr (OD_DKV_CHAINS) { sa = sa_[ki]; pa = pa_[ki]; }
+                else {
 #pragma unroll
-                for (int s = 0; s < NS; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
+                    for (int s = 0; s < NS; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
+                }
                 f32x4 e = sa;
                 if constexpr (!PRE) e = od_mul4s(sa, c);
                 f32x4 p;
@@ -697,6 +800,29 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
     const int nfull = kragged ? 0 : L / 64;
     for (int qt = 0; qt < nfull; qt++) tile(qt, std::false_type{});
     for (int qt = nfull; qt < nqt; qt++) tile(qt, std::true_type{});
+    if constexpr (RB) {
+        // dV as it is; dK through the backward of k's RMSNorm + RoPE, straight into the qkv projection's gradient
+        f32x4 dwacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) dwacc[dt] = (f32x4)(0.f);
+#pragma unroll
+        for (int ki = 0; ki < NK; ki++) {
+            const int row = key0 + ki * 16 + x;
+            const bool valid = row < L;
+            const int rc = valid ? row : L - 1;
+            if (valid) {
+                T* dvr = dv + ((size_t)b * L + row) * lddv + h * HD;
+#pragma unroll
+                for (int dt = 0; dt < ND; dt++) st4(dvr + dt * 16 + 4 * g, dvacc[ki][dt][0], dvacc[ki][dt][1], dvacc[ki][dt][2], dvacc[ki][dt][3]);
+            }
+            f32x4 a[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) a[dt] = dkacc[ki][dt < ND ? dt : 0] * out_scale;
+            qk_rope_norm_bwd_row(a, rb, (long)b * L + rc, rc, h, g, valid, (bf16_t*)dk + ((size_t)b * L + rc) * lddk + h * HD, dwacc);
+        }
+        qk_rope_norm_bwd_dw(dwacc, rb.dw, x, g);
+        return;
+    }
 #pragma unroll
     for (int ki = 0; ki < NK; ki++) {
         const int row = key0 + ki * 16 + x;
@@ -721,11 +847,11 @@ __global__ __launch_bounds__(64 * NWK, (NWK == 8 ? 1 : 2)) void flash_bwd_dkv_ke
 
 // dQ: block owns 4 waves x NQ*16 queries; loop over 64-key tiles.
 //   S^T = K Q^T ; dP^T = V dO^T ; dS^T = P^T*(dP^T - delta)*scale ; dQ^T += K^T dS^T
-template <class T, int HD, int NQ, int NW, bool PRE>
+template <class T, int HD, int NQ, int NW, bool PRE, bool RB = false>
 __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
                                                               const T* __restrict__ v, int ldv, const T* __restrict__ dout, int lddo,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              T* __restrict__ dq, int lddq, int B, int H, int L, float scale) {
+                                                              T* __restrict__ dq, int lddq, int B, int H, int L, float scale, RopeBwdEpi rb) {
     using St = Stage<T, HD>;
     constexpr int NS = HD / 32, ND = HD / 16, QB = NW * NQ * 16;
     constexpr int NSTAGE = St::TR ? 2 : 1;
@@ -833,6 +959,23 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
     const int nfull = L / 64;
     for (int kt = 0; kt < nfull; kt++) tile(kt, std::false_type{});
     if (nfull < nkt) tile(nfull, std::true_type{});
+    if constexpr (RB) {
+        f32x4 dwacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) dwacc[dt] = (f32x4)(0.f);
+#pragma unroll
+        for (int qi = 0; qi < NQ; qi++) {
+            const int row = q0 + qi * 16 + x;
+            const bool valid = row < L;
+            const int rc = valid ? row : L - 1;
+            f32x4 a[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) a[dt] = dqacc[qi][dt < ND ? dt : 0] * out_scale;
+            qk_rope_norm_bwd_row(a, rb, (long)b * L + rc, rc, h, g, valid, (bf16_t*)dq + ((size_t)b * L + rc) * lddq + h * HD, dwacc);
+        }
+        qk_rope_norm_bwd_dw(dwacc, rb.dw, x, g);
+        return;
+    }
 #pragma unroll
     for (int qi = 0; qi < NQ; qi++) {
         const int row = q0 + qi * 16 + x;
@@ -847,8 +990,179 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 ? 3 : 2)) void flash_bwd_dq_kerne
     }
 }
 
-// (The 32x32x16-MFMA form of the dQ kernel, the norm + RoPE backward in the dQ / dK epilogues, the interleaved-chain and 8-wave dK/dV variants and the
-// timing-only modes of rounds 2-3 live in variants/attn_r03_variants.hip: tools/build_variant.sh compiles that file in place of this one on demand.)
+// ======================================================================== dQ, bf16, head_dim 64, 32x32x16 MFMA
+// Round 3.  The two-wave-per-SIMD attention loops sit where the SIMD's issue port and its matrix pipe are both full (the 16x16x32 dQ loop:
+// 323 issues per wave and tile at ~4.5 cycles each against 96 x 16 MFMA cycles), so what pays is fewer ISSUES per flop: a 32x32x16 MFMA
+// does the work of two 16x16x32 for one issue slot.  Same formulation as flash_fwd32_kernel — S^T = K Q'^T with the query as the
+// accumulator COLUMN, the dS^T accumulators feeding dQ'^T += K^T dS^T directly through the key permutation that the K^T operand reproduces
+// with transpose reads of the SAME staged K tile.
+// Registers decide the rest: a lane-constant C operand (-lse, -delta) of a 32x32 tile is a 16-register splat, and two query blocks per wave
+// cannot afford two of them each.  So lse is taken out of the loop algebraically.  With n = round(lse') (lse' = lse * log2 e, q' = q * scale * log2 e):
+//     dS^T = 2^(S^T - lse') (dP^T - delta) = 2^(-frac) * 2^(S^T) * [ V (2^-n dO)^T - 2^-n delta ]
+// i.e. the dO fragments are multiplied by the power of two 2^-n ONCE at kernel entry (exact), the dP chain starts at -2^-n delta, the S
+// chain starts at the inline constant 0, and the remaining per-query factor 2^(n - lse') in [0.7, 1.42] goes to the dQ row at the end.
+// 2^(S^T) is not shifted by a row maximum here: |q'.k| has to stay below ~120 (87 nats; with RMS-normed q and k of head_dim 64 it is
+// bounded by 11.6 |w_q| |w_k|), beyond which the result is Inf/NaN — loudly, never silently wrong.
+#ifndef OD_DQ32_NQB
+#define OD_DQ32_NQB 2     // 32-query blocks per wave
+#endif
+template <int NW, int NQB>
+__global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dq32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                                 const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int lddo,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                 bf16_t* __restrict__ dq, int lddq, int B, int H, int L) {
+    using St = Stage<bf16_t, 64>;
+    constexpr int HD = 64, QB = NW * NQB * 32, STAGE = 2 * St::BYTES;
+    static_assert(NW == 4, "the K/V tiles are streamed as 2 + 2 one-KiB pieces per wave");
+    OD_DYN_SMEM(smem);   // 2 stages x (K row-major, V row-major), 16-byte slots swizzled by swz32
+    const int nqt = (L + QB - 1) / QB;
+    int qt, bh;
+    if (!attn_block_coords(nqt, B * H, qt, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), c32 = lane & 31, hi = lane >> 5, x = lane & 15, g4 = lane >> 4;
+    const int q0 = qt * QB + wave * NQB * 32;
+    const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
+    const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
+    const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
+    const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
+    auto dma = [&](int kt, unsigned char* st) {
+        const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u, sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
+        od_buffer_lds16(rk, vk, sk, st + wave * 1024);
+        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
+        od_buffer_lds16(rv, vv, sv, st + St::BYTES + wave * 1024);
+        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + St::BYTES + (wave + 4) * 1024);
+    };
+    // Q'^T and (2^-n dO)^T fragments (B operands): column = query, k = 16 s4 + 8 hi + j
+    s16x8 fq[NQB][4], fdo[NQB][4];
+    f32x16_t dinit[NQB];
+    float fscale[NQB];
+    f32x16_t dqacc[NQB][2];
+#pragma unroll
+    for (int qi = 0; qi < NQB; qi++) {
+        int row = q0 + qi * 32 + c32; row = row < L ? row : L - 1;
+        const bf16_t* qp = q + ((size_t)b * L + row) * ldq + h * HD;
+        const bf16_t* dp = dout + ((size_t)b * L + row) * lddo + h * HD;
+        const float l2 = lse[((size_t)b * H + h) * L + row] * LOG2E;
+        const float n = rintf(l2);
+        const float e = od_exp2(-n);                       // a power of two: scaling by it is exact
+        fscale[qi] = od_exp2(n - l2) * LN2;                // dL/dq' -> dL/d(q * scale): the factor ln 2 of the pre-multiplied q
+        dinit[qi] = (f32x16_t)(-delta[((size_t)b * H + h) * L + row] * e);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            fq[qi][s4] = *(const s16x8*)(qp + s4 * 16 + hi * 8);
+            float t[8];
+            od_ld8(dp + s4 * 16 + hi * 8, t);
+            u32x4 w;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) w[jj] = od_pack_bf2(t[2 * jj] * e, t[2 * jj + 1] * e);
+            fdo[qi][s4] = __builtin_bit_cast(s16x8, w);
+        }
+        dqacc[qi][0] = (f32x16_t)(0.f); dqacc[qi][1] = (f32x16_t)(0.f);
+    }
+    const int nkt = (L + 63) / 64;
+    int offK[4], offT[2][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) offK[s4] = tile32_off(c32, (s4 * 16 + hi * 8) * 2);                 // + kb * 4096; V tile: + St::BYTES
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int e = 0; e < 2; e++)                                                                   // K^T chunk of the K tile; + 2048 per 16-key slab
+            offT[db][e] = tile32_off(4 * (g4 >> 1) + (x >> 2) + 8 * e, (db * 32 + 16 * (g4 & 1) + 4 * (x & 3)) * 2);
+    OD_DRAIN_VMEM();
+    dma(0, smem);
+    OD_WAIT_VMCNT(0);
+    __syncthreads();
+
+    auto tile = [&](int kt, const unsigned char* st, unsigned char* st_next, auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        if (kt + 1 < nkt) dma(kt + 1, st_next);
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            s16x8 fds[NQB][2];
+            {
+                s16x8 fk[4], fv[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    fk[s4] = *(const s16x8*)(st + offK[s4] + kb * 4096);
+                    fv[s4] = *(const s16x8*)(st + St::BYTES + offK[s4] + kb * 4096);
+                }
+#pragma unroll
+                for (int qi = 0; qi < NQB; qi++) {
+                    f32x16_t sa = od_mma32(fk[0], fq[qi][0], (f32x16_t)(0.f));
+                    f32x16_t pa = od_mma32(fv[0], fdo[qi][0], dinit[qi]);
+#pragma unroll
+                    for (int s4 = 1; s4 < 4; s4++) { sa = od_mma32(fk[s4], fq[qi][s4], sa); pa = od_mma32(fv[s4], fdo[qi][s4], pa); }
+#if defined(OD_DQ32_PK)
+                    {     // A/B: the 16 products as packed multiplies
+                        f32x16_t pp;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) pp[r] = od_exp2(sa[r]);
+                        pa = pp * pa;
+                        sa = (f32x16_t)(1.f);
+                    }
+#define OD_DQ32_P(r) (pa[r])
+#else
+#define OD_DQ32_P(r) (od_exp2(sa[r]) * pa[r])
+#endif
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        u32x4 w;
+#pragma unroll
+                        for (int jj = 0; jj < 4; jj++) {
+                            const int r0 = 8 * sl + 2 * jj;
+                            float d0 = OD_DQ32_P(r0), d1 = OD_DQ32_P(r0 + 1);
+                            if constexpr (MASKED) {      // ragged last tile only: keys >= L (their K / V rows read as zero, not as -inf)
+                                if (kt * 64 + kb * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * hi >= L) d0 = 0.f;
+                                if (kt * 64 + kb * 32 + ((r0 + 1) & 3) + 8 * ((r0 + 1) >> 2) + 4 * hi >= L) d1 = 0.f;
+                            }
+                            w[jj] = od_pack_bf2(d0, d1);
+                        }
+                        fds[qi][sl] = __builtin_bit_cast(s16x8, w);
+                    }
+                }
+            }
+            // dQ'^T += K^T dS^T : A = K^T fragment (rows = features of block db), two transpose reads per 16-key slab
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    const s16x4 a0 = od_lds_tr_read((const bf16_t*)(st + offT[db][0] + (kb * 2 + sl) * 2048));
+                    const s16x4 a1 = od_lds_tr_read((const bf16_t*)(st + offT[db][1] + (kb * 2 + sl) * 2048));
+                    s16x8 fkt;
+                    fkt[0] = a0[0]; fkt[1] = a0[1]; fkt[2] = a0[2]; fkt[3] = a0[3];
+                    fkt[4] = a1[0]; fkt[5] = a1[1]; fkt[6] = a1[2]; fkt[7] = a1[3];
+#pragma unroll
+                    for (int qi = 0; qi < NQB; qi++) dqacc[qi][db] = od_mma32(fkt, fds[qi][sl], dqacc[qi][db]);
+                }
+        }
+        OD_WAIT_VMCNT(0);
+        __syncthreads();
+    };
+    unsigned char* const s0 = smem;
+    unsigned char* const s1 = smem + STAGE;
+    const int nfull = L / 64;
+    int kt = 0;
+    for (; kt + 1 < nfull; kt += 2) {
+        tile(kt, s0, s1, std::false_type{});
+        tile(kt + 1, s1, s0, std::false_type{});
+    }
+    if (kt < nfull) { if (kt & 1) tile(kt, s1, s0, std::false_type{}); else tile(kt, s0, s1, std::false_type{}); kt++; }
+    if (nfull < nkt) { if (kt & 1) tile(kt, s1, s0, std::true_type{}); else tile(kt, s0, s1, std::true_type{}); }
+#pragma unroll
+    for (int qi = 0; qi < NQB; qi++) {
+        const int row = q0 + qi * 32 + c32;
+        if (row < L) {
+            bf16_t* drow = dq + ((size_t)b * L + row) * lddq + h * HD;
+            const float f = fscale[qi];
+#pragma unroll
+            for (int db = 0; db < 2; db++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+                    st4(drow + db * 32 + 8 * t4 + 4 * hi, dqacc[qi][db][4 * t4] * f, dqacc[qi][db][4 * t4 + 1] * f,
+                        dqacc[qi][db][4 * t4 + 2] * f, dqacc[qi][db][4 * t4 + 3] * f);
+        }
+    }
+}
 
 #ifndef OD_ATTN_NW
 #define OD_ATTN_NW 4      // waves per workgroup of the bf16 forward / dQ kernels.  6 (K/V streamed once per 192 queries) measured 0.71x: a 6-wave group lands 2,2,1,1 on the SIMDs and a second group no longer fits at 3 waves/SIMD
@@ -905,8 +1219,12 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 template <class T, int HD, int NK, int NQ, bool PRE>
 int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout,
                int lddo, const float* lse, float* delta, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H,
-               int L, float scale, hipStream_t st, const AttnAux* aux = nullptr) {
+               int L, float scale, hipStream_t st, const RopeBwdEpi* rbq = nullptr, const RopeBwdEpi* rbk = nullptr, const AttnAux* aux = nullptr) {
     const long M = (long)B * L;
+    constexpr bool CAN_RB = std::is_same<T, bf16_t>::value && HD == 64;
+    const bool use_rb = CAN_RB && rbq && rbk;
+    if ((rbq || rbk) && !use_rb) return OD_ERR_UNSUPPORTED;
+    const RopeBwdEpi none{};
     OD_LAUNCH((attn_delta_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const T*)o, ldo, (const T*)dout, lddo, delta,
               B, H, L, HD);
     // Two-stream form: with a side stream (od_attn_aux_create) the dQ kernel runs beside the dK/dV kernel — both depend on delta alone — and its
@@ -915,21 +1233,48 @@ int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 #if !defined(OD_EMU)
     static const int two_streams = od_env_int("OD_BWD_2STREAM", 1);      // 0: ignore the side stream (A/B)
     if (aux && two_streams) {
-        // a side stream that cannot be forked into (another device's, a destroyed one) is not an error of this call: run single-stream
-        if (hipEventRecord(aux->fork, st) == hipSuccess && hipStreamWaitEvent(aux->side, aux->fork, 0) == hipSuccess) st_q = aux->side;
-        else (void)hipGetLastError();
+        if (hipEventRecord(aux->fork, st) != hipSuccess || hipStreamWaitEvent(aux->side, aux->fork, 0) != hipSuccess) return OD_ERR_ARG;
+        st_q = aux->side;
     }
 #endif
-    constexpr int NWK = 4;
+#ifndef OD_DKV_NW
+#define OD_DKV_NW 4      // waves per dK/dV workgroup (bf16): 8 = the Q/dO tiles streamed once per 256 keys
+#endif
+    constexpr int NWK = Stage<T, HD>::TR ? OD_DKV_NW : 4;
     const int gk = attn_grid((L + 16 * NWK * NK - 1) / (16 * NWK * NK), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), dim3(gk), dim3(64 * NWK),
-                  ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk,
-                  (const T*)v, ldv, (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale);
+#define OD_LAUNCH_DYN_X(...) OD_LAUNCH_DYN(__VA_ARGS__)      /* lets an argument-list macro expand first */
+#define DKV_ARGS dim3(gk), dim3(64 * NWK), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + 2 * Stage<T, HD>::NT) * Stage<T, HD>::BYTES + 512)), st, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
+              (const T*)dout, lddo, lse, (const float*)delta, (T*)dk, lddk, (T*)dv, lddv, B, H, L, scale
+    if constexpr (CAN_RB) {
+        if (use_rb) OD_LAUNCH_DYN_X((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE, true>), DKV_ARGS, *rbk);
+        else OD_LAUNCH_DYN_X((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), DKV_ARGS, none);
+    } else
+        OD_LAUNCH_DYN_X((flash_bwd_dkv_kernel<T, HD, NK, NWK, PRE>), DKV_ARGS, none);
+#undef DKV_ARGS
+#ifndef OD_DQ32
+#define OD_DQ32 0        // 1 = the 32x32x16 dQ kernel above for bf16 / head_dim 64 / pre-multiplied q.  Measured (profiles/r03a_ab_attn.txt, same box,
+                         // backward of one layer): 16x16x32 kernel 24.10 / 24.12 ms, this one 24.45 / 24.37 ms (one query block per wave: 26.0 / 25.6) —
+                         // halving the MFMA issue count does not pay here either (round 2 saw the same for dK/dV), so it is kept as a variant only
+#endif
+    if (OD_DQ32 && use_rb) return OD_ERR_UNSUPPORTED;      // the 32x32 variant has no norm + RoPE epilogue
+    if constexpr (OD_DQ32 && std::is_same<T, bf16_t>::value && HD == 64 && PRE) {
+        constexpr int NQB = OD_DQ32_NQB;
+        const int gq32 = attn_grid((L + 4 * NQB * 32 - 1) / (4 * NQB * 32), B * H);
+        OD_LAUNCH_DYN((flash_bwd_dq32_kernel<4, NQB>), dim3(gq32), dim3(256), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                      (const bf16_t*)v, ldv, (const bf16_t*)dout, lddo, lse, (const float*)delta, (bf16_t*)dq, lddq, B, H, L);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr int NWQ = Stage<T, HD>::TR ? OD_ATTN_NW : 4;
     const int gq = attn_grid((L + 16 * NQ * NWQ - 1) / (16 * NQ * NWQ), B * H);
-    OD_LAUNCH_DYN((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), dim3(gq), dim3(64 * NWQ),
-                  ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st_q, (const T*)q, ldq, (const T*)k, ldk,
-                  (const T*)v, ldv, (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale);
+#define DQ_ARGS dim3(gq), dim3(64 * NWQ), ((Stage<T, HD>::TR ? 2 : 1) * ((2 + Stage<T, HD>::NT) * Stage<T, HD>::BYTES)), st_q, (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, \
+              (const T*)dout, lddo, lse, (const float*)delta, (T*)dq, lddq, B, H, L, scale
+    if constexpr (CAN_RB) {
+        if (use_rb) OD_LAUNCH_DYN_X((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE, true>), DQ_ARGS, *rbq);
+        else OD_LAUNCH_DYN_X((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), DQ_ARGS, none);
+    } else
+        OD_LAUNCH_DYN_X((flash_bwd_dq_kernel<T, HD, NQ, NWQ, PRE>), DQ_ARGS, none);
+#undef DQ_ARGS
 #if !defined(OD_EMU)
     if (st_q != st) { if (hipEventRecord(aux->join, st_q) != hipSuccess || hipStreamWaitEvent(st, aux->join, 0) != hipSuccess) return OD_ERR_ARG; }
 #endif
@@ -1005,7 +1350,7 @@ extern "C" int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const vo
                                      void* aux, void* stream) {
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
-#define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st, (const AttnAux*)aux
+#define ARGS q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, lddq, dk, lddk, dv, lddv, B, H, L, scale, st, nullptr, nullptr, (const AttnAux*)aux
 // Register tiles of the bf16 / hd 64 backward: 16-row tiles per wave.  Per streamed tile every wave pays a fixed budget — its LDS-DMA
 // pieces, the row-wise AND transposed fragment reads of the whole tile pair, the barrier — whatever it owns (removing the in-loop DMA takes
 // 25.5 -> 20.2 ms; deeper tile rings, trimmed loops and 8-wave workgroups change nothing or lose: profiles/r02l_ab_bwd_tile_budget.txt), so
@@ -1024,4 +1369,25 @@ extern "C" int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const vo
 #undef BWD
 #undef ARGS
     return OD_ERR_UNSUPPORTED;
+}
+
+// The backward of attention AND of the q / k RMSNorm + RoPE in front of it (attn.py:77-82), for a fused qkv projection: q', k' are the
+// normed + rotated operands the forward attended with, `qkv` holds the PRE-norm projection [M, 3*H*hd] (q | k | v column blocks), and
+// dqkv receives the gradient of that projection directly — dq and dk never exist in memory.  bf16, head_dim 64 only.
+extern "C" int od_flash_attn_bwd_qkrope(int dtype, const void* q, int ldq, const void* k, int ldk, const void* qkv, int ldqkv, const void* o,
+                                        int ldo, const void* dout, int lddo, const float* lse, float* delta, void* dqkv, int lddqkv,
+                                        const float* wq, const float* wk, const float* table, float* dwq, float* dwk, int B, int H, int L,
+                                        int hd, float scale, float eps, float q_scale, int q_prescaled, void* stream) {
+    if (dtype != OD_BF16 || hd != 64) return OD_ERR_UNSUPPORTED;
+    if (!qkv || !dqkv || !wq || !wk || !table || !dwq || !dwk) return OD_ERR_ARG;
+    if (ldq % 8 || ldk % 8 || ldqkv % 8 || ldo % 8 || lddo % 8 || lddqkv % 8) return OD_ERR_ALIGN;
+    const int dh = H * hd;
+    const bf16_t* pre = (const bf16_t*)qkv;
+    bf16_t* g = (bf16_t*)dqkv;
+    const RopeBwdEpi rbq{pre, ldqkv, wq, table, dwq, eps, q_scale}, rbk{pre + dh, ldqkv, wk, table, dwk, eps, 1.f};
+    hipStream_t st = (hipStream_t)stream;
+    const void* v = pre + 2 * dh;
+#define ARGS q, ldq, k, ldk, v, ldqkv, o, ldo, dout, lddo, lse, delta, g, lddqkv, g + dh, lddqkv, g + 2 * dh, lddqkv, B, H, L, scale, st, &rbq, &rbk
+    return q_prescaled ? launch_bwd<bf16_t, 64, OD_BWD_NK, OD_BWD_NQ, true>(ARGS) : launch_bwd<bf16_t, 64, OD_BWD_NK, OD_BWD_NQ, false>(ARGS);
+#undef ARGS
 }

@@ -79,7 +79,7 @@ class DenoiserEngine:
         # (the sampler's hipGraph) is stale from then on
         self.generation = 0
         self._attn_aux = None
-        self._vendor = None
+        self._attn_ws = None          # workspace of the fused (5-pass) attention backward, per (B, H, L)
 
     # ------------------------------------------------------------------ parameters
     def P(self, name: str) -> torch.Tensor:
@@ -140,15 +140,7 @@ class DenoiserEngine:
         return self._packed[name + (".T" if T else "")]
 
     def plain_gemm(self, A: torch.Tensor, W: torch.Tensor, bias, C: torch.Tensor):
-        """C = A W^T (+ bias), no epilogue.  od_gemm_nt (the 4-wave persistent kernel at training size) runs these; with OD_VENDOR_GEMM=1 the four
-        long-K, N <= 512 products of a layer go to the vendor library's kernel instead (3-5 % ahead there, behind on every K = 512 shape:
-        profiles/r03u_ab_sustained.txt; ops.VendorGemm), falling back to od_gemm_nt when the library cannot be bound or declines."""
-        if (A.is_cuda and A.dtype == torch.bfloat16 and A.shape[0] >= 32768 and W.shape[0] <= 512 and A.shape[1] >= 1024
-                and os.environ.get("OD_VENDOR_GEMM", "0") == "1"):
-            if self._vendor is None:
-                self._vendor = ops.VendorGemm(A.device)
-            if self._vendor.gemm_nt(A, W, bias, C):
-                return
+        """C = A W^T (+ bias), no epilogue: od_gemm_nt (the 4-wave persistent kernel at training size)."""
         ops.gemm_nt(A, W, bias, C, x3=self.x3)
 
     # ------------------------------------------------------------------ plan / workspace
@@ -277,33 +269,49 @@ class DenoiserEngine:
         ops.uhead_fwd(xt, self._uhead_w(), fsum, self.U)
         ops.uhead_tail(fsum, self.ws.t["umod"], self.P("u_out.weight"), self.P("u_out.bias"), u, L, self.model.u_scale)
 
-    def fused_rope_bwd(self) -> bool:
-        """Whether the backward of the q / k RMSNorm + RoPE runs in the attention backward's epilogues (od_flash_attn_bwd_qkrope: dq, dk never
-        exist in memory, the 3.2 GB od_qk_norm_rope_bwd pass is gone).  Built, parity-tested and MEASURED SLOWER at the bench shape
-        (profiles/r03f_ab_rope_fused.txt: 26.7-26.9 ms against 25.5 + 0.67 ms; step 373-374 against 370 ms on the same box): the epilogue's
-        row loads / stores cost 0.4 ms per layer where no other wave of the workgroup computes, and its weight-gradient atomics (9.8 M per layer
-        onto 128 addresses) another 0.7.  Off unless OD_FUSED_ROPE_BWD=1."""
+    def attn_bwd_passes(self) -> int:
+        """L x L x hd MFMA passes the attention backward of this plan executes (5 = the algorithmic count: one fused kernel; 7 = the
+        dK/dV + dQ kernel pair, which recomputes S and dP)."""
+        from . import _lib
+        return int(_lib.lib().cdll.od_flash_attn_bwd_fused_passes() if self.fused_attn_bwd() else _lib.lib().cdll.od_flash_attn_bwd_passes())
+
+    def fused_attn_bwd(self) -> bool:
+        """Whether the attention backward runs as od_flash_attn_bwd_fused: one kernel, the 5 algorithmic MFMA passes, dQ summed over key blocks by
+        the chain through the XCD's L2 (bf16, head_dim 64).  Default for L >= 4096 — a key block has to trail its predecessor by ~1.5 query
+        tiles, and consecutive key blocks start (L / 64) / (CUs per XCD) tiles apart, so short sequences would run the chain in lock step;
+        OD_ATTN_BWD_FUSED=0 / 1 forces the two-kernel / the fused path."""
         import os
-        return self.dtype == torch.bfloat16 and self.hd == 64 and os.environ.get("OD_FUSED_ROPE_BWD", "0") == "1"
+        if self.dtype != torch.bfloat16 or self.hd != 64:
+            return False
+        env = os.environ.get("OD_ATTN_BWD_FUSED", "")
+        if env in ("0", "1"):
+            return env == "1"
+        return self.L >= 4096
 
     def attn_bwd_launch(self, i: int, dy: torch.Tensor, delta: torch.Tensor, dqkv: torch.Tensor, core_only: bool = False):
         """The backward of layer i's attention core + q / k norm + RoPE exactly as `backward` launches it: dy = gradient of the attention
         output, dqkv <- gradient of the qkv projection; norm weight gradients accumulate.  `core_only` (bench.py's roofline leg): just
-        od_flash_attn_bwd (delta, dK/dV, dQ) as the step launches it, without the separate norm + RoPE backward pass that follows it."""
+        the attention backward as the step launches it, without the separate norm + RoPE backward pass that follows it."""
         t, dh, p = self.ws.t, self.dh, f"net.layers.{i}."
         qk, qkv, y, lse = t[f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
         wq, wk = self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight")
         gq, gk = self.G(p + "attn.q_norm.weight"), self.G(p + "attn.k_norm.weight")
         scale = 1.0 / math.sqrt(self.hd)
-        if self.fused_rope_bwd():
-            ops.flash_attn_bwd_qkrope(qk[:, :dh], qk[:, dh:], qkv, y, dy, lse, delta, dqkv, wq, wk, t["rope"], gq, gk,
-                                      self.B, self.H, self.L, self.hd, scale, FP32_EPS, q_scale=self.q_scale, q_prescaled=True)
-            return
         dqk = self.buf("d.qk", (self.M, 2 * dh))
-        if self._attn_aux is None and qk.is_cuda:
-            self._attn_aux = ops.AttnAux()                  # side stream + events: the dQ kernel runs beside the dK/dV kernel
-        ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
-                           dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, scale, q_prescaled=True, aux=self._attn_aux)
+        if self.fused_attn_bwd():
+            if self._attn_ws is None or self._attn_ws.shape != (self.B, self.H, self.L) or self._attn_ws.buf.device != qk.device:
+                self._attn_ws = ops.FusedAttnBwdWorkspace(self.B, self.H, self.L, qk.device)
+            ops.flash_attn_bwd_fused(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:],
+                                     self.B, self.H, self.L, self.hd, scale, self._attn_ws, q_prescaled=True)
+        else:
+            if (self._attn_aux is None or self._attn_aux.device != qk.device) and qk.is_cuda:
+                if self._attn_aux is not None:
+                    self._attn_aux.close()
+                with torch.cuda.device(qk.device):          # the side stream and its events belong to the tensors' device (ADVICE r3)
+                    self._attn_aux = ops.AttnAux()          # side stream + events: the dQ kernel runs beside the dK/dV kernel
+                self._attn_aux.device = qk.device
+            ops.flash_attn_bwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, delta, dqk[:, :dh], dqk[:, dh:],
+                               dqkv[:, 2 * dh:], self.B, self.H, self.L, self.hd, scale, q_prescaled=True, aux=self._attn_aux)
         if not core_only:
             ops.qk_norm_rope_bwd(qkv, wq, wk, t["rope"], dqk, dqkv, gq, gk, self.B, self.L, self.H, self.hd, FP32_EPS, q_scale=self.q_scale)
 

@@ -75,66 +75,6 @@ def gemm_nt(A, W, bias, C, epilogue=OD_EPI_NONE, accumulate=False, x3=False):
                           epilogue, int(accumulate), _stream(A))
 
 
-class VendorGemm:
-    """Handle of the vendor-library GEMM path (od_vendor_gemm_create: hipBLASLt bound at run time) plus the workspace it may use.
-    `available` is False when the library could not be bound — callers then stay on od_gemm_nt."""
-
-    WORKSPACE_BYTES = 64 << 20
-
-    def __init__(self, device):
-        import ctypes
-        self.handle = ctypes.c_void_p()
-        self.workspace = None
-        # PyTorch's own copy: it is already loaded in this process, and a second hipBLASLt (the ROCm tree's) cannot be — its rocRoller
-        # symbols clash with the loaded one's (observed on the MI355X image: dlopen fails with an undefined rocRoller symbol)
-        path = os.environ.get("OD_HIPBLASLT_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "libhipblaslt.so")
-        rc = _lib.lib().cdll.od_vendor_gemm_create(ctypes.byref(self.handle), path.encode()) if os.path.exists(path) else -1
-        self.available = rc == 0 and bool(self.handle)
-        if self.available:
-            self.workspace = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
-            self.available = self._self_test(device)
-
-    def _self_test(self, device) -> bool:
-        """The library is bound through a header of another release than the binary (ROCm's header, PyTorch's library): one small product
-        with a bias is checked against od_gemm_nt before the path is trusted.  Any disagreement turns the path off."""
-        g = torch.Generator().manual_seed(0)
-        A = torch.randn(256, 1024, generator=g).to(torch.bfloat16).to(device)
-        W = (torch.randn(512, 1024, generator=g) * 0.05).to(torch.bfloat16).to(device)
-        b = torch.randn(512, generator=g).to(device)
-        C1 = torch.zeros(256, 512, dtype=torch.bfloat16, device=device)
-        C2 = torch.zeros_like(C1)
-        self.available = True
-        ok = self.gemm_nt(A, W, b, C1)
-        gemm_nt(A, W, b, C2)
-        if not ok:
-            return False
-        err = float((C1.float() - C2.float()).norm() / C2.float().norm())
-        return err < 1e-2
-
-    def gemm_nt(self, A, W, bias, C) -> bool:
-        """C = A W^T (+ bias) through the library; False (nothing launched) when it declines the shape."""
-        if not self.available:
-            return False
-        M, K = A.shape
-        N = W.shape[0]
-        assert W.shape[1] == K and tuple(C.shape) == (M, N) and A.dtype == W.dtype == C.dtype
-        _f32(bias)
-        rc = _lib.lib().cdll.od_gemm_nt_vendor(self.handle, dt_code(A.dtype), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), M, N, K,
-                                               _p(self.workspace), self.workspace.numel(), _stream(A))
-        return rc == 0
-
-    def close(self):
-        if self.handle:
-            _lib.lib().od_vendor_gemm_destroy(self.handle)
-            self.handle = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
 def gemm_nt_qkrope(A, W, bias, C, wq, wk, table, L, H, hd, eps, x3=False, q_scale=1.0):
     """qkv projection with q/k RMSNorm + RoPE in the epilogue (forward-only): C[:, :2*H*hd] normed + rotated."""
     code, W = mm_code(A.dtype, x3, W), _w(W)
@@ -326,13 +266,35 @@ def flash_attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, L, hd, scale, q
                                      B, H, L, hd, scale, int(q_prescaled), aux.handle if aux is not None else None, _stream(q))
 
 
-def flash_attn_bwd_qkrope(q, k, qkv, o, do, lse, delta, dqkv, wq, wk, table, dwq, dwk, B, H, L, hd, scale, eps, q_scale=1.0,
-                          q_prescaled=False):
-    """Attention backward with the backward of the q / k RMSNorm + RoPE in its epilogues (bf16, head_dim 64)."""
-    _f32(lse, delta, wq, wk, table, dwq, dwk)
-    _lib.lib().od_flash_attn_bwd_qkrope(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(qkv), _ld(qkv), _p(o), _ld(o), _p(do), _ld(do),
-                                        _p(lse), _p(delta), _p(dqkv), _ld(dqkv), _p(wq), _p(wk), _p(table), _p(dwq), _p(dwk),
-                                        B, H, L, hd, scale, eps, q_scale, int(q_prescaled), _stream(q))
+class FusedAttnBwdWorkspace:
+    """Caller-owned device memory of od_flash_attn_bwd_fused for one (B, H, L): control block + chain flags (zeroed once here; every call
+    leaves them zero), the start values (-lse', -delta) and the running dQ tiles.  One instance serves every layer of a step (same stream)."""
+
+    def __init__(self, B, H, L, device):
+        import ctypes
+        total, zero = ctypes.c_long(), ctypes.c_long()
+        _lib.lib().od_flash_attn_bwd_fused_ws_bytes(B, H, L, ctypes.byref(total), ctypes.byref(zero))
+        self.shape = (B, H, L)
+        self.bytes = total.value
+        assert zero.value <= self.bytes
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+        self.buf[:zero.value].zero_()          # once: control block and running tiles (a zero tile never carries a valid tag)
+
+    def status(self) -> int:
+        """The sticky error word (0 = every launch processed all of its jobs).  Synchronises the device."""
+        import ctypes
+        err = ctypes.c_int(-1)
+        _lib.lib().od_flash_attn_bwd_fused_status(_p(self.buf), ctypes.byref(err))
+        return err.value
+
+
+def flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, scale, ws: FusedAttnBwdWorkspace, q_prescaled=False):
+    """The 5-pass fused attention backward (bf16, head_dim 64): dq, dk, dv from one kernel, dQ summed over key blocks by the L2 chain."""
+    _f32(lse)
+    assert ws.shape == (B, H, L), (ws.shape, (B, H, L))
+    _lib.lib().od_flash_attn_bwd_fused(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(do), _ld(do),
+                                       _p(lse), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), B, H, L, hd, scale, int(q_prescaled),
+                                       _p(ws.buf), ws.bytes, _stream(q))
 
 
 # ---------------------------------------------------------------- feed-forward

@@ -216,6 +216,7 @@ template <class T> inline T __shfl_down(T v, int d, int width = 64) { (void)widt
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __logf(float x) { return logf(x); }

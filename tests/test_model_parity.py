@@ -255,11 +255,37 @@ def test_bf16_training_step_tiny(dev, name):
 
 
 @pytest.mark.gpu
-def test_bf16_training_step_full_width():
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_bf16_training_step_full_width(monkeypatch, fused):
+    """... with the attention backward as the two-kernel pair (7 MFMA passes) and as od_flash_attn_bwd_fused (5; the default from L = 4096)."""
     from osu_dreamer_amd import _lib
     _lib._lib = None
     _lib.lib()
+    monkeypatch.setenv("OD_ATTN_BWD_FUSED", fused)
     run_bf16_training_case("train_bf16_full_d2_b2_l96", torch.device("cuda:0"))
+
+
+def test_fused_attention_backward_in_the_step(dev, monkeypatch):
+    """The training step's backward with od_flash_attn_bwd_fused (forced: L is short) against the same step with the two-kernel attention
+    backward — bf16, head_dim 64, two key blocks, ragged tiles: every gradient agrees to the bf16 noise of dq, and the loss is identical."""
+    d = O.Dims(global_cond_dim=64, backbone_dim=128, n_heads=2, head_dim=64, depth=2, expand=2, radius=1, u_head_dim=16)
+    P = O.init_params(d, seed=11)
+    data = O.synthetic_batch(d, 2, 230, seed=12)
+    grads = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("OD_ATTN_BWD_FUSED", fused)
+        tr = make_trainer(d, P, dev)
+        model = tr.diffusion
+        model.compute_dtype = torch.bfloat16
+        dd = {k: v.to(dev) for k, v in data.items()}
+        opt = tr.configure_optimizers()["optimizer"]
+        opt.zero_grad()
+        loss, _ = tr(model, dd["h"], dd["z"], dd["s"], None, t=dd["t"], x0=dd["x0"])
+        loss.backward()
+        assert model.engine.fused_attn_bwd() == (fused == "1") and model.engine.attn_bwd_passes() == (5 if fused == "1" else 7)
+        grads[fused] = (float(loss.detach()), model.arena.grad.detach().cpu().clone())
+    assert grads["0"][0] == grads["1"][0]
+    assert rel_l2(grads["1"][1], grads["0"][1]) < 2e-3
 
 
 # ------------------------------------------------------------------------------------------------------------------
