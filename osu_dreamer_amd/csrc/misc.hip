@@ -359,7 +359,9 @@ __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __res
 }
 // dx[b][k] += sum_n dpre[b][n] W[n][k]: block = 32 samples x 256 columns over a 32-row slice of N, one thread per column with the 32
 // sample accumulators in registers; the dpre tile is staged transposed ([n][b]) so a thread reads four samples per (broadcast) LDS read;
-// the slices meet in dx through fp32 atomics (dx is zeroed by the launcher when it does not accumulate).
+// the slices meet in dx through fp32 atomics (dx is zeroed by the launcher when it does not accumulate): the style / global-conditioning
+// gradients (ssg1 / ssg2 / u_mod / proj_style backward) are therefore reproducible to fp32 rounding, not bit for bit, run to run — like the
+// weight-gradient GEMMs' split-M sums (tests/test_ddp_rccl.py holds a DDP step to 1e-4 of a plain step for that reason).
 constexpr int LS_NR = 32;
 __global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __restrict__ W, const float* __restrict__ dpre,
                                                               float* __restrict__ dx, int B, int N, int K) {

@@ -88,12 +88,13 @@ def gemm_nt_qkrope(A, W, bias, C, wq, wk, table, L, H, hd, eps, x3=False, q_scal
 
 def gemm_nt_qkrope_split(A, W, bias, C, qk_out, wq, wk, table, L, H, hd, eps, x3=False, q_scale=1.0):
     """qkv projection for training: C keeps the pre-norm values, qk_out[:, :2*H*hd] gets q/k normed + rotated."""
+    code, W = mm_code(A.dtype, x3, W), _w(W)          # a weight pre-split for the fp32-as-3-x-bf16 product (pack_weights(x3=True)) arrives wrapped
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and tuple(C.shape) == (M, N) and tuple(qk_out.shape) == (M, 2 * H * hd)
     assert A.dtype == W.dtype == C.dtype == qk_out.dtype
     _f32(bias, wq, wk, table)
-    _lib.lib().od_gemm_nt_qkrope_split(mm_code(A.dtype, x3), _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), _p(qk_out),
+    _lib.lib().od_gemm_nt_qkrope_split(code, _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), _p(qk_out),
                                        _ld(qk_out), M, N, K, _p(wq), _p(wk), _p(table), L, H, hd, eps, q_scale, _stream(A))
 
 

@@ -202,6 +202,24 @@ def test_edge_shapes_vs_oracle(dev, B, L, Ba, steps):
             assert rel_l2(p.grad, ref_grads[k]) < 1e-3, k
 
 
+def test_bf16x3_forward_when_the_qkv_epilogue_does_not_apply(dev):
+    """f32_matmul = 'bf16x3' with an odd head count (2 * H * hd not a multiple of 128): the no-grad forward takes the qkv projection's
+    two-kernel path (od_gemm_nt_qkrope_split) and has to unwrap the pre-split weight like every other GEMM wrapper."""
+    d = O.Dims(global_cond_dim=64, backbone_dim=96, n_heads=3, head_dim=32, depth=2, expand=2, radius=1, u_head_dim=16)
+    P = O.init_params(d, seed=41)
+    data = O.synthetic_batch(d, 2, 50, seed=42)
+    g = torch.Generator().manual_seed(43)
+    xt = torch.randn(2, d.emb_dim, 50, generator=g)
+    m = DiffusionModel(d.emb_dim, d.a_dim, d.style_dim, margs(d))
+    m.load_state_dict(P)
+    m = m.to(dev)
+    m.f32_matmul = "bf16x3"
+    with torch.no_grad():
+        u, v = m(data["h"].to(dev), data["s"].to(dev), xt.to(dev))
+    ref_u, ref_v = O.forward(data["h"], data["s"], xt, P, d)
+    assert rel_l2(u, ref_u) < 5e-5 and rel_l2(v, ref_v) < 2e-4
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # bf16 training step (model.yml:12 `precision: bf16-mixed` — what the headline bench runs) against the reference's own
 # bf16-autocast loss and gradients.  Bound per tensor: error vs the reference's fp32 gradient <= BF16_K x the error of the

@@ -1,5 +1,5 @@
 """One NT GEMM shape, a few launches, for counter runs: python3 tools/mb_nt_one.py N K [vendor]
-(OD_NT_W4=1 in the environment selects the 4-wave kernel)."""
+(the 4-wave kernel is the default; OD_NT_W4=0 in the environment selects the 8-wave kernel)."""
 import os, sys
 import torch
 sys.path.insert(0, os.getcwd())

@@ -12,7 +12,7 @@ fi
 for var in own8 own4 vendor; do
   for set in "${sets[@]}"; do
     rm -rf $out/p
-    unset OD_NT_W4; arg=""
+    export OD_NT_W4=0; arg=""            # the 4-wave kernel has been the default since round 3: the 8-wave one has to be asked for
     [ $var = own4 ] && export OD_NT_W4=1
     [ $var = vendor ] && arg=vendor
     timeout 300 rocprofv3 --pmc $set -d $out/p -o res -- python3 tools/mb_nt_one.py $N $K $arg > $out/p.log 2>&1

@@ -9,7 +9,7 @@ for lib in "$@"; do
     rm -rf $out/p
     unset OSU_DREAMER_HIP_LIB; arg=""; flt=gemm_nt
     export OD_NT_W4=1
-    if [ "$lib" = vendor ]; then arg=vendor; flt=Cijk; elif [ "$lib" = own8 ]; then unset OD_NT_W4; elif [ "$lib" != "-" ]; then export OSU_DREAMER_HIP_LIB=$PWD/$lib; fi
+    if [ "$lib" = vendor ]; then arg=vendor; flt=Cijk; elif [ "$lib" = own8 ]; then export OD_NT_W4=0; elif [ "$lib" != "-" ]; then export OSU_DREAMER_HIP_LIB=$PWD/$lib; fi
     timeout 300 rocprofv3 --pmc $set -d $out/p -o res -- python3 tools/mb_nt_one.py $N $K $arg > $out/p.log 2>&1
     echo "== $lib" >> $out/pmc_variants.txt
     python3 tools/rocpd_pmc_dispatch.py $(find $out/p -name "*.db" | head -1) $flt 2>&1 | tail -1 >> $out/pmc_variants.txt
