@@ -155,6 +155,93 @@ def load_sampler_parity():
     return None, None
 
 
+class PowerSampler:
+    """Samples `rocm-smi` (board power, shader clock) from a host thread while a region runs, so that the line says what box / what
+    throttle state the number was taken in.  Every field is None where rocm-smi is absent or unreadable (an ordinary user on the GPU
+    box may read it; nothing here changes a GPU setting)."""
+
+    SMI = "/opt/rocm/bin/rocm-smi"
+
+    def __init__(self, device_index=0, period_s=0.25):
+        import threading
+        self.dev, self.period = device_index, period_s
+        self.samples, self._stop, self._thr = [], threading.Event(), None
+
+    def _read(self):
+        import re, subprocess
+        try:
+            o = subprocess.run([self.SMI, "-d", str(self.dev), "-P", "-c"], capture_output=True, text=True, timeout=5).stdout
+        except Exception:
+            return None
+        p = re.search(r"Power \(W\):\s*([\d.]+)", o)
+        c = re.search(r"sclk clock level:?\s*\d*:?\s*\((\d+)Mhz\)", o)
+        return (float(p.group(1)) if p else None, float(c.group(1)) if c else None)
+
+    def __enter__(self):
+        import threading
+
+        def loop():
+            while not self._stop.is_set():
+                r = self._read()
+                if r is not None:
+                    self.samples.append(r)
+                self._stop.wait(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thr.join(timeout=10)
+
+    def cap_w(self):
+        import re, subprocess
+        try:
+            o = subprocess.run([self.SMI, "-d", str(self.dev), "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
+            m = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", o)
+            return float(m.group(1)) if m else None
+        except Exception:
+            return None
+
+    def summary(self):
+        pw = [p for p, _ in self.samples if p is not None]
+        ck = [c for _, c in self.samples if c is not None]
+        return {"power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "clk_mhz_mean": round(sum(ck) / len(ck), 1) if ck else None,
+                "power_cap_w": self.cap_w(), "samples": len(self.samples),
+                "source": "rocm-smi -P -c sampled from a host thread over the timed region (the sampled sclk is the instantaneous level, not a cycle average)"}
+
+
+def mfma_calibration(device, seconds=2.0):
+    """~2 s of bare v_mfma_f32_16x16x32_bf16 on pseudo-random operands through the C ABI (od_mfma_calibrate): the dense bf16 rate THIS box
+    sustains under its power cap, measured in this run.  ms_per_step x this figure is comparable between boxes and rounds."""
+    import ctypes
+    from osu_dreamer_amd import _lib
+    scratch = torch.empty(256 * 1024, dtype=torch.float32, device=device)
+    flops = ctypes.c_double()
+    st = torch.cuda.current_stream(device).cuda_stream
+
+    def launch(iters):
+        _lib.lib().od_mfma_calibrate(scratch.data_ptr(), iters, ctypes.byref(flops), st)
+    launch(2000)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n, t0 = 0, time.time()
+    with PowerSampler(device.index or 0) as ps:
+        e0.record()
+        while time.time() - t0 < seconds:
+            for _ in range(5):
+                launch(20000)
+            n += 5
+            torch.cuda.synchronize()
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    out = {"sustained_tflops": round(n * flops.value / ms / 1e9, 1), "seconds": round(ms / 1e3, 2),
+           "kernel": "od_mfma_calibrate: bare v_mfma_f32_16x16x32_bf16, pseudo-random operands, one wave per SIMD on every CU"}
+    out.update({k: v for k, v in ps.summary().items() if k in ("power_w_mean", "clk_mhz_mean")})
+    return out
+
+
 def roofline_of_dominant_kernel(tr, B, L):
     """Re-launch the step's dominant kernel (od_flash_attn_bwd: the attention backward of one layer) alone on the step's
     own buffers and time it with HIP events on the launch stream.  `achieved` counts ALGORITHMIC FLOPs: 5 MFMA passes of
@@ -229,7 +316,7 @@ def cpu_baseline(L_cpu=2048):
     O.adamw_ema_step(P, grads, m, vv, ema, 1, 3e-4, clip=coef, first_ema=True)
     dt = time.time() - t0
     frames_per_s = L_cpu / dt
-    return {"value": frames_per_s / (32 * 8192), "unit": "train-steps/s (32x8192-frame step equivalent)",
+    return {"value": frames_per_s / (32 * 8192), "unit": "train-steps/s (32x8192-frame step equivalent, EXTRAPOLATED by frames from the timed sample)",
             "cores": cores, "cpu": cpu_model(), "kind": "port",
             "sample": f"1 fp32 train step, batch 1 x {L_cpu} frames, {dt:.1f} s, {frames_per_s:.0f} frames/s; "
                       f"attention cost grows with L, so this over-states the CPU rate at L=8192"}
@@ -427,12 +514,14 @@ def main():
     if reducer is not None:
         reducer.exposed_ms()                   # drop the warm-up's events
         reducer.time_exposed = True            # HIP events either side of the compute stream's wait for the exchange (no host sync)
+    sampler = PowerSampler(device.index or 0)
     barrier()
-    t0 = time.time()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    barrier()
-    dt = time.time() - t0
+    with sampler:
+        t0 = time.time()
+        for i in range(args.steps):
+            loss = step(args.warmup + i)
+        barrier()
+        dt = time.time() - t0
     per_rank = None
     if ddp:
         import torch.distributed as dist
@@ -475,6 +564,9 @@ def main():
             "final_loss": round(final_loss, 4),
             "workspace_gb": round(tr.diffusion.engine.ws.bytes / 2**30, 1),
         }
+        # what box / what throttle state this line was taken in (rank 0's GPU): board power and shader clock sampled over the timed region
+        line.update({k: v for k, v in sampler.summary().items() if k in ("clk_mhz_mean", "power_w_mean", "power_cap_w")})
+        line["power_sampling"] = {k: v for k, v in sampler.summary().items() if k in ("samples", "source")}
         if ddp:
             line["collective"] = {"backend": "RCCL via od_allreduce_grads", "version": reducer.comm.version,
                                   "exchange": "od_allreduce_grads per arena segment (187.5 MB fp32 per step), overlapped with backward",
@@ -487,8 +579,11 @@ def main():
                                   "ms_per_step_min_rank": round(float(per_rank[:, 0].min()), 2),
                                   "ms_per_step_max_rank": round(float(per_rank[:, 0].max()), 2),
                                   "ms_per_step_per_rank": [round(float(x), 2) for x in per_rank[:, 0]],
-                                  "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+                                  "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                                  "comm_stream_priority": int(os.environ.get("OD_COMM_STREAM_PRIORITY", "0"))}
         if not args.no_extras and world == 1:
+            line["calibration"] = mfma_calibration(device)
+            line["ms_per_step_x_sustained_tflops"] = round(ms * line["calibration"]["sustained_tflops"], 1)     # comparable between boxes and rounds
             line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
             line["pcie_inclusive"] = h2d_leg(batch, device, ms)
             line["forward_64x8192"] = forward_target_shape(tr, device)

@@ -314,6 +314,13 @@ int od_graph_end(void* stream, void** graph_exec_out);
 int od_graph_launch(void* graph_exec, void* stream);
 int od_graph_destroy(void* graph_exec);
 
+/* ---- measurement aid ------------------------------------------------------------------ */
+/* One launch of a bare-MFMA kernel (v_mfma_f32_16x16x32_bf16 on pseudo-random operands, one wave per SIMD on every CU, nothing else in the
+ * loop): `iters` x 64 MFMAs per wave; *flops_out = the FLOPs of the launch.  bench.py times ~2 s of it beside every measurement: the dense bf16
+ * rate this board sustains under its power cap (the pool's boxes differ by +-5 %), against which a step time of that box can be read.
+ * scratch: device memory, >= 1 KiB per CU.  Not part of the reference's path. */
+int od_mfma_calibrate(float* scratch, int iters, double* flops_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

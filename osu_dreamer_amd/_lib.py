@@ -26,7 +26,7 @@ _CTYPES = {
     "float*": ctypes.c_void_p, "const float*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "void**": ctypes.POINTER(ctypes.c_void_p),
     "const char*": ctypes.c_char_p,
-    "long*": ctypes.POINTER(ctypes.c_long), "int*": ctypes.POINTER(ctypes.c_int),
+    "long*": ctypes.POINTER(ctypes.c_long), "int*": ctypes.POINTER(ctypes.c_int), "double*": ctypes.POINTER(ctypes.c_double),
 }
 
 

@@ -86,6 +86,7 @@ class GradBucketReducer:
         self.overlap = overlap
         self._handles: List = []
         self._comm_stream: Optional[torch.cuda.Stream] = None
+        self.bucket_log: list = []
         self._done = set()
         # exposed communication: HIP events on the compute stream either side of its wait for the side stream, i.e. how long the
         # optimizer had to wait for the exchange after the backward's own kernels were done (0 when the overlap is perfect)
@@ -137,9 +138,14 @@ class GradBucketReducer:
         self._done.add(name)
         s, e = self.segments[name]
         g = self.model.arena.ensure_grad()[s:e]
+        self.bucket_log.append((name, e - s))   # the order the collectives were enqueued in (tests: identical on every rank)
         if g.is_cuda and self.overlap:
             if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(g.device)
+                # OD_COMM_STREAM_PRIORITY: 0 (default) = a plain side stream; -1 = high, 1 = LOW priority — the exchange's kernels then
+                # take CUs only when the backward leaves them free (for the first real multi-GPU run to A/B against CU contention)
+                import os
+                prio = int(os.environ.get("OD_COMM_STREAM_PRIORITY", "0"))
+                self._comm_stream = torch.cuda.Stream(g.device, priority=prio) if prio else torch.cuda.Stream(g.device)
             self._comm_stream.wait_stream(torch.cuda.current_stream(g.device))
             with torch.cuda.stream(self._comm_stream):
                 self._handles.append((self._reduce(g), g))
@@ -167,6 +173,7 @@ class GradBucketReducer:
                 cur.wait_stream(self._comm_stream)
         self._handles.clear()
         self._done.clear()
+        self.bucket_log = self.bucket_log[-64:]
 
     def exposed_ms(self, reset: bool = True) -> List[float]:
         """Per step since the last reset: milliseconds the compute stream spent waiting for the gradient exchange (synchronises)."""

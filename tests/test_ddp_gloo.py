@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import denoiser_oracle as O
     from osu_dreamer_amd import _lib
@@ -50,18 +50,23 @@ def _worker(rank, world, port, out_dir):
     opt.step()
     tr.on_train_batch_end()
     torch.save({"p": tr.diffusion.arena.data.clone(), "ema": tr.diffusion_ema.module.arena.data.clone(),
-                "g": tr.diffusion.arena.grad.clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
+                "g": tr.diffusion.arena.grad.clone(), "buckets": list(red.bucket_log)}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_averaged_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_n_rank_step_matches_averaged_oracle(tmp_path, world):
+    """World sizes 2 and 8 (the size the driver's scaling run uses): every rank ends the step with identical weights / EMA / gradients,
+    equal to the oracle's step on the mean of the ranks' gradients, and every rank reduced its buckets in the same order."""
     from kernel_backend import build_emu
     build_emu()
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
-    r1 = torch.load(tmp_path / "rank1.pt")
-    assert torch.equal(r0["p"], r1["p"]) and torch.equal(r0["ema"], r1["ema"]) and torch.equal(r0["g"], r1["g"])
+    for r in range(1, world):
+        rr = torch.load(tmp_path / f"rank{r}.pt")
+        assert torch.equal(r0["p"], rr["p"]) and torch.equal(r0["ema"], rr["ema"]) and torch.equal(r0["g"], rr["g"])
+        assert rr["buckets"] == r0["buckets"], "ranks must enqueue the same buckets in the same order (a collective per bucket)"
+    assert len(r0["buckets"]) >= 3 and sum(n for _, n in r0["buckets"]) == r0["g"].numel()
 
     from oracle import denoiser_oracle as O
     from osu_dreamer_amd.model import DiffusionModel
@@ -72,7 +77,7 @@ def test_two_rank_step_matches_averaged_oracle(tmp_path):
     for rank in range(world):
         data = O.synthetic_batch(d, 2, 24, seed=60 + rank)
         grads.append(O.loss_and_grads(P, d, data["h"], data["z"], data["s"], data["t"], data["x0"])[2])
-    avg = {k: (grads[0][k] + grads[1][k]) / 2 for k in P}
+    avg = {k: sum(g[k] for g in grads) / world for k in P}
     _, coef = O.clip_coef(avg, 1.0)
     m = {k: torch.zeros_like(v) for k, v in P.items()}
     vv = {k: torch.zeros_like(v) for k, v in P.items()}
@@ -166,6 +171,25 @@ def test_launcher_spawns_n_ranks(tmp_path):
     finally:
         del os.environ["WORLD_SIZE"]
     assert launch.spawn_ranks_if_needed(1, ["x"]) is None
+
+
+def test_launcher_runs_eight_ranks_that_rendezvous(tmp_path):
+    """`devices: 8` — the launcher's eight torchrun children find each other on 127.0.0.1 and complete a collective (gloo here; the GPU job
+    hands the same rendezvous the RCCL unique id)."""
+    from osu_dreamer_amd import launch
+    script = tmp_path / "rank_sum.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "torch.set_num_threads(1)\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(dist.get_rank())])\n"
+        "dist.all_reduce(t)\n"
+        "open(os.path.join(sys.argv[1], 'sum' + os.environ['RANK']), 'w').write(f'{int(t.item())} {dist.get_world_size()}')\n"
+        "dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    rc = launch.spawn_ranks_if_needed(8, [str(script), str(tmp_path)], env=env)
+    assert rc == 0
+    assert [(tmp_path / f"sum{r}").read_text() for r in range(8)] == ["28 8"] * 8
 
 
 def test_bench_gpus_flag_starts_ranks(monkeypatch):
