@@ -164,15 +164,23 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
     const float c = scale * FB_LOG2E, out_scale = PRE ? FB_LN2 : scale;
     int my_jobs = 0;
 
-    for (;;) {
-        if (threadIdx.x == 0) *s_job = fb_atomic_inc(&sync->head[xcc]);
-        __syncthreads();
-        const int job = od_uniform(*s_job);
-        __syncthreads();                                   // everyone has read the job before thread 0 may overwrite it
+    // Jobs.  The next job's number is drawn by thread 0 at the START of a job's last query tile and left in LDS in front of that tile's barrier:
+    // when the key waves come out of their loop they know where to go, and fetch the next key block's K / V fragments while the query waves are
+    // still finishing the chain of this one (~2 tiles) — no queue round trip, no extra barrier and no idle key waves between jobs.
+    if (threadIdx.x == 0) s_job[0] = fb_atomic_inc(&sync->head[xcc]);
+    __syncthreads();
+    int job = od_uniform(s_job[0]), jpar = 0;
+    for (;; jpar ^= 1) {
         if (job >= jobs_per_xcd) break;
         my_jobs++;
         const int bh = (job / nkb) * 8 + xcc, kblk = job % nkb;
-        if (bh >= BH) continue;
+        if (bh >= BH) {                                    // a queue slot past the last (batch, head): draw again, everybody together
+            __syncthreads();
+            if (threadIdx.x == 0) s_job[jpar ^ 1] = fb_atomic_inc(&sync->head[xcc]);
+            __syncthreads();
+            job = od_uniform(s_job[jpar ^ 1]);
+            continue;
+        }
         const int b = bh / H, h = bh % H;
         const bf16_t* qb = q + (size_t)b * L * ldq + h * 64;
         const bf16_t* kb_ = k + (size_t)b * L * ldk + h * 64;
@@ -206,8 +214,11 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             const int ds_off0 = (wave * 48 + x) * 128 + ((g ^ fb_swz(x)) << 4);
             __syncthreads();                               // tile 0 has landed (query waves waited for their DMA)
             unsigned long long pk_bar = 0;
+            int next_job = 0;
             auto tile = [&](int qt, auto masked_t) FB_INLINE {
                 constexpr bool MASKED = decltype(masked_t)::value;
+                const bool last_tile = qt == nqt - 1;
+                if (last_tile && threadIdx.x == 0) next_job = fb_atomic_inc(&sync->head[xcc]);     // used a tile later
                 const unsigned char* st = smem + (qt & 1) * FB_STAGE;
                 unsigned char* dsb = smem + 2 * FB_STAGE + (qt & 1) * FB_DS;
                 const unsigned char* tQ = st;
@@ -252,12 +263,13 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                             od_frag_set4(fds[ki], th, ds[0], ds[1], ds[2], ds[3]);
                         }
                     }
-                    // publish dS: fragment u of key tile ki = queries {32u + 4g + r, 32u + 16 + 4g + r} of key row (wave, ki, x): one 16-byte slot
-#pragma unroll
-                    for (int ki = 0; ki < NK; ki++) { if (!(FB_X & 4)) *(s16x8*)(dsb + ((ds_off0 ^ (u * 64)) + ki * 2048)) = fds[ki].v; }
                     // dV^T += dO^T P ; dK^T += Q^T dS     (A rows = features, k = permuted queries of this half, cols = keys)
+                    // and, one per feature tile, the publication of dS: fragment u of key tile ki = queries {32u + 4g + r, 32u + 16 + 4g + r} of
+                    // key row (wave, ki, x), one 16-byte slot.  A ds_write_b128 holds the LDS store path for ~13 cycles; three in a row in front
+                    // of the MFMAs were fully exposed (1.5 ms per call), one between each group of six MFMAs hides behind them.
 #pragma unroll
                     for (int dt = 0; dt < 4; dt++) {
+                        if (dt < NK && !(FB_X & 4)) *(s16x8*)(dsb + ((ds_off0 ^ (u * 64)) + dt * 2048)) = fds[dt].v;
                         od_frag<bf16_t> fot, fqt;
                         frag_cols<128, 128>(fot, tO, tO, dt * 16, x, u, g);
                         frag_cols<128, 128>(fqt, tQ, tQ, dt * 16, x, u, g);
@@ -266,8 +278,10 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                             dvacc[ki][dt] = od_mma(fot, fp[ki], dvacc[ki][dt]);
                             dkacc[ki][dt] = od_mma(fqt, fds[ki], dkacc[ki][dt]);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (last_tile && threadIdx.x == 0) s_job[jpar ^ 1] = next_job;
                 const unsigned long long tb0 = FB_CLK();
                 __syncthreads();
                 pk_bar += FB_CLK() - tb0;
@@ -302,9 +316,10 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
 #pragma unroll
             for (int s = 0; s < 6; s++) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < 8; j++) {                                // clamped address + select: 48 independent loads, no branches
                     const int key = kblk * KB + 32 * s + 8 * g + j;
-                    fkt[s].v[j] = key < L ? (short)kb_[(size_t)key * ldk + 16 * hh + x] : (short)0;
+                    const short kv = (short)kb_[(size_t)(key < L ? key : L - 1) * ldk + 16 * hh + x];
+                    fkt[s].v[j] = key < L ? kv : (short)0;
                 }
             }
             // Q / dO tile streaming: piece = 8 rows x 128 B; this wave moves pieces hh and hh + 4 of both tiles; waves 0 / 1 also move the
@@ -524,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             if (FB_PROF && threadIdx.x == 256) { for (int i = 0; i < 6; i++) atomicAdd(&sync->prof[2 + i], ph[i]); }
             FB_WAIT_ALL();
         }
+        job = od_uniform(s_job[jpar ^ 1]);               // left there in front of the last tile's barrier
     }
     // ---- leave: the last workgroup out checks that every job ran and re-arms the control block for the next launch
     if (threadIdx.x == 0) {
