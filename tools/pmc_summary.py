@@ -48,7 +48,7 @@ if jpath:
     byname = {r[0]: r for r in rows}
     def pick(sub):
         return [r for n, r in byname.items() if sub in n]
-    bwd = pick("flash_bwd") + pick("attn_delta")
+    bwd = pick("flash_bwd") + pick("attn_delta") + pick("fb_prep")          # od_flash_attn_bwd_fused = fb_prep_kernel + flash_bwd_fused_kernel
     fwd = pick("flash_fwd")
     out = {"B": 32, "L": 8192, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --steps 1 --warmup 1 --no-extras (tools/pmc_step.sh); read = 2 x FETCH_SIZE",
            "od_flash_attn_bwd": {"read_bytes": sum(r[3] for r in bwd), "write_bytes": sum(r[4] for r in bwd), "kernels": [r[0] for r in bwd]},
@@ -60,7 +60,7 @@ if jpath:
         if "flash_bwd" in n: return "attention_bwd"
         if "gemm_nt" in n: return "gemm_nt"
         if "gemm_tn" in n: return "gemm_tn"
-        if any(k in n for k in ("rmsnorm", "swiglu", "qk_norm_rope", "dwconv", "attn_delta", "final_proj", "silu", "adamw", "sqnorm", "cl_to_frames")): return "row_kernels"
+        if any(k in n for k in ("rmsnorm", "swiglu", "qk_norm_rope", "dwconv", "attn_delta", "fb_prep", "final_proj", "silu", "adamw", "sqnorm", "cl_to_frames")): return "row_kernels"
         return "other"
     agg = defaultdict(lambda: [0.0, 0.0, 0.0])      # time_us, bytes, mfma-busy x time
     for n, calls, us, rd, wr, mfu, clk in rows:

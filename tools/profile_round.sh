@@ -20,7 +20,7 @@ rm -rf $out/kt $out/pmc/p1 $out/pmc/p2 $out/pmc/p3 $out/s_bf16 $out/s_f32 $out/s
 timeout 600 python3 -m pytest tests/test_sampler50.py -m gpu -q > $out/sampler50_test.txt 2>&1; cp gpurun_out/sampler_parity.json $out/sampler_parity.json
 # the bench line quotes the counter / parity records of THIS build: put them where bench.py looks (copy the same files into the
 # repository's profiles/ afterwards; a record whose kernel_src_sha differs from the library's is ignored by bench.py)
-round=${2:-r03}
+round=${2:-r04}
 cp $out/traffic.json profiles/${round}_traffic.json; cp $out/sampler_parity.json profiles/${round}_sampler_parity.json
 timeout 900 python3 bench.py > $out/bench.json 2> $out/bench.err
 tail -c 600 $out/bench.json

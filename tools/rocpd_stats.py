@@ -35,6 +35,10 @@ tot = sum(a[1] for a in agg.values())
 print(f"{'kernel':78s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'share':>7s}")
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{n[:78]:78s} {c:7d} {t / 1e6:10.2f} {t / c / 1e3:10.1f} {100 * t / tot:6.2f}%")
+fused = [t for n, (c, t) in agg.items() if "flash_bwd_fused_kernel" in n or "fb_prep_kernel" in n]
+nfused = max([c for n, (c, t) in agg.items() if "flash_bwd_fused_kernel" in n] or [0])
+if nfused:
+    print(f"{'od_flash_attn_bwd_fused per call: fb_prep_kernel + flash_bwd_fused_kernel (one stream)':78s} {nfused:7d} {sum(fused) / 1e6:10.2f} {sum(fused) / nfused / 1e3:10.1f}   (sum of the two rows)")
 if calls:
     print(f"{'od_flash_attn_bwd per call: union of delta + dK/dV || dQ (two streams)':78s} {len(calls):7d} {bwd_union / 1e6:10.2f} {bwd_union / len(calls) / 1e3:10.1f}   (rows above overlap)")
 print(f"{'TOTAL':78s} {sum(a[0] for a in agg.values()):7d} {tot / 1e6:10.2f}")
