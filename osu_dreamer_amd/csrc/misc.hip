@@ -1,6 +1,7 @@
 // Boundary/layout kernels, depthwise Conv1d, per-sample linears, weight packing.
 #include "od_common.h"
 #include "od_api_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -244,15 +245,49 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x
                 for (int k = 0; k < 8; k++) { wx[j][k] = 0.f; wy[j][k] = 0.f; }
             }
         }
-        for (int i = 0; i < DW_RUN_BWD; i++) {
+        // The rows entering the window are requested DW_PF iterations before they are used (raw 16-byte rows in a small register ring, the
+        // loop unrolled by the ring size so that its slots are compile-time): the one-row-per-iteration form consumed each load in the
+        // iteration that issued it — two waves per SIMD with two loads in flight each, 43 % of the HBM rate (profiles/r03_pmc_step.txt).
+        constexpr int DW_PF = 2;
+        typedef typename std::conditional<sizeof(T) == 2, u32x4, f32x4>::type row_t;      // 8 channels as loaded (bf16: one 16-byte word)
+        row_t px[DW_PF][sizeof(T) == 2 ? 1 : 2], py[DW_PF][sizeof(T) == 2 ? 1 : 2];
+        auto fetch = [&](int ln, int slot) {
+            if (ln < L) {
+#pragma unroll
+                for (int h2 = 0; h2 < (sizeof(T) == 2 ? 1 : 2); h2++) {
+                    px[slot][h2] = *(const row_t*)(xb + (size_t)ln * ldx + h2 * 4);
+                    py[slot][h2] = *(const row_t*)(yb + (size_t)ln * lddy + h2 * 4);
+                }
+            } else {
+#pragma unroll
+                for (int h2 = 0; h2 < (sizeof(T) == 2 ? 1 : 2); h2++) { px[slot][h2] = (row_t)(0); py[slot][h2] = (row_t)(0); }
+            }
+        };
+        auto unpack = [&](const row_t (&r)[sizeof(T) == 2 ? 1 : 2], float (&o8)[8]) {
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; i2++) {
+                    union { uint32_t u; float f; } lo, hi;
+                    lo.u = r[0][i2] << 16; hi.u = r[0][i2] & 0xffff0000u;
+                    o8[2 * i2] = lo.f; o8[2 * i2 + 1] = hi.f;
+                }
+            } else {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; i2++) { o8[i2] = r[0][i2]; o8[4 + i2] = r[1][i2]; }
+            }
+        };
+#pragma unroll
+        for (int pf = 0; pf < DW_PF; pf++) fetch(l0 + R + pf, pf);
+        for (int i0 = 0; i0 < DW_RUN_BWD; i0 += DW_PF) {
+          if (l0 + i0 >= L) break;
+#pragma unroll
+          for (int pf = 0; pf < DW_PF; pf++) {
+            const int i = i0 + pf;
             const int l = l0 + i;
             if (l >= L) break;
-            const int ln = l + R;
-            if (ln < L) { od_ld8(xb + (size_t)ln * ldx, wx[KS - 1]); od_ld8(yb + (size_t)ln * lddy, wy[KS - 1]); }
-            else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) { wx[KS - 1][k] = 0.f; wy[KS - 1][k] = 0.f; }
-            }
+            unpack(px[pf], wx[KS - 1]);
+            unpack(py[pf], wy[KS - 1]);
+            fetch(l + R + DW_PF, pf);
             float o[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -271,6 +306,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x
             for (int j = 0; j < KS - 1; j++)
 #pragma unroll
                 for (int k = 0; k < 8; k++) { wx[j][k] = wx[j + 1][k]; wy[j][k] = wy[j + 1][k]; }
+          }
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
