@@ -282,6 +282,190 @@ __global__ __launch_bounds__(64 * NW, (NW >= 6 || NQT == 1 ? 3 : 2)) void flash_
     }
 }
 
+// ======================================================================== forward, fp32 tensors, 3 x bf16 MFMAs per product, head_dim 64
+// The sampler's compliant mode (f32_matmul = "bf16x3"; round 4).  Same formulation as flash_fwd_kernel, but the (hi, lo) bf16 split of K and V
+// happens ONCE per tile, when the workgroup stages it: a thread turns its 16-byte fp32 chunk into two 8-byte bf16 chunks and stores them into a
+// hi and a lo plane of the LDS stage (row-major bf16 images, 16 KB per operand like the fp32 tile they replace).  The generic kernel staged fp32
+// (plus a transposed fp32 copy of V, four 4-byte stores per chunk) and split every fragment at read time — in each of the four waves, ~450
+// vector-ALU operations per wave and key tile beside 96 MFMAs: the kernel was bound by that (119 us per launch at the sampler's size, 0.51 PF/s
+// executed).  Now K fragments are 16-byte reads of the planes, V^T fragments transpose reads of the row-major planes (no transposed copy), the
+// probabilities are split as before (they are formed in registers), and the staging itself is the only split work left: a quarter of it.
+template <int NW, bool PRE, int NQT>
+__global__ __launch_bounds__(64 * NW, 2) void flash_fwd_x3p_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                                   const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                                   float* __restrict__ lse, int B, int H, int L, float scale) {
+    constexpr int HD = 64, PL = 64 * 128;          // one bf16 plane of a 64-row tile
+    constexpr int STAGE = 4 * PL;                  // K hi, K lo, V hi, V lo
+    static_assert(NW == 4, "the staging maps 1024 chunks of a tile onto 256 threads");
+    OD_DYN_SMEM(smem);
+    constexpr int QB = NW * 16 * NQT;
+    const int nqt = (L + QB - 1) / QB;
+    int qt, bh;
+    if (!attn_block_coords(nqt, B * H, qt, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const float* qb = q + (size_t)b * L * ldq + h * HD;
+    const float* kb = k + (size_t)b * L * ldk + h * HD;
+    const float* vb = v + (size_t)b * L * ldv + h * HD;
+    const int q0 = qt * QB + wave * 16 * NQT;
+    const float c = PRE ? 1.f : scale * LOG2E;
+
+    od_frag<f32x3_t> fq[NQT][2];
+#pragma unroll
+    for (int qi = 0; qi < NQT; qi++) {
+        int row = q0 + qi * 16 + x; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s = 0; s < 2; s++) od_frag_load(fq[qi][s], (const f32x3_t*)(qb + (size_t)row * ldq + s * 32 + g * 8));
+    }
+    f32x4 oacc[NQT][4];
+    float mref[NQT], lrun[NQT];
+#pragma unroll
+    for (int qi = 0; qi < NQT; qi++) {
+        mref[qi] = 0.f; lrun[qi] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) oacc[qi][dt] = (f32x4)(0.f);
+    }
+    const float inv_c = 1.0f / c;
+    const int nkt = (L + 63) / 64;
+    // staging: chunk cc = threadIdx.x + 256 i (i = 0..3) of the 64 x 16 fp32 chunks of a tile: row cc / 16, floats 4 (cc % 16) .. + 3
+    u32x4 rk[4], rv[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int cc = threadIdx.x + 256 * i, row = cc >> 4, ch = cc & 15;
+            int gr = kt * 64 + row; gr = gr < L ? gr : L - 1;
+            rk[i] = *(const u32x4*)(kb + (size_t)gr * ldk + ch * 4);
+            rv[i] = *(const u32x4*)(vb + (size_t)gr * ldv + ch * 4);
+        }
+    };
+    auto lstore = [&](unsigned char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int cc = threadIdx.x + 256 * i, row = cc >> 4, ch = cc & 15;
+            const int off = tile_off<128>(row, ch * 8);
+            u32x2 hi, lo;
+            const f32x4 fk4 = __builtin_bit_cast(f32x4, rk[i]), fv4 = __builtin_bit_cast(f32x4, rv[i]);
+            uint32_t h0, l0, h1, l1;
+            od_split2(fk4[0], fk4[1], h0, l0); od_split2(fk4[2], fk4[3], h1, l1);
+            hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+            *(u32x2*)(st + off) = hi; *(u32x2*)(st + PL + off) = lo;
+            od_split2(fv4[0], fv4[1], h0, l0); od_split2(fv4[2], fv4[3], h1, l1);
+            hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+            *(u32x2*)(st + 2 * PL + off) = hi; *(u32x2*)(st + 3 * PL + off) = lo;
+        }
+    };
+    gload(0); lstore(smem);
+    __syncthreads();
+    auto tile = [&](int kt, auto masked_t, auto first_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        constexpr bool FIRST = decltype(first_t)::value;
+        const unsigned char* st = smem + (kt & 1) * STAGE;
+        if (kt + 1 < nkt) gload(kt + 1);
+        f32x4 e[NQT][4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; t4++) {
+            od_frag<f32x3_t> fk[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                fk[s].hi = *(const s16x8*)(st + tile_off<128>(t4 * 16 + x, (s * 32 + g * 8) * 2));
+                fk[s].lo = *(const s16x8*)(st + PL + tile_off<128>(t4 * 16 + x, (s * 32 + g * 8) * 2));
+            }
+#pragma unroll
+            for (int qi = 0; qi < NQT; qi++) {
+                f32x4 a = (f32x4)(-mref[qi]);
+#pragma unroll
+                for (int s = 0; s < 2; s++) a = od_mma(fk[s], fq[qi][s], a);
+                if constexpr (PRE) e[qi][t4] = a; else e[qi][t4] = a * c;
+            }
+        }
+        const int kbase = kt * 64;
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int qi = 0; qi < NQT; qi++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (kbase + t4 * 16 + 4 * g + r >= L) e[qi][t4][r] = NEG_BIG;
+        }
+        float mx[NQT];
+#pragma unroll
+        for (int qi = 0; qi < NQT; qi++) {
+            mx[qi] = fmaxf(fmaxf(e[qi][0][0], e[qi][0][1]), fmaxf(e[qi][0][2], e[qi][0][3]));
+#pragma unroll
+            for (int t4 = 1; t4 < 4; t4++)
+                mx[qi] = fmaxf(mx[qi], fmaxf(fmaxf(e[qi][t4][0], e[qi][t4][1]), fmaxf(e[qi][t4][2], e[qi][t4][3])));
+        }
+        if (FIRST || __any(fmaxf(mx[0], mx[NQT - 1]) > OD_FWD_SLACK)) {      // the lazy reference moves (always on the first tile)
+#pragma unroll
+            for (int qi = 0; qi < NQT; qi++) {
+                float m = mx[qi];
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const float d = FIRST ? m : fmaxf(m, 0.f);
+                if constexpr (!FIRST) {
+                    const float alpha = od_exp2(-d);
+                    lrun[qi] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 4; dt++) oacc[qi][dt] *= alpha;
+                }
+                mref[qi] += d * inv_c;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++) e[qi][t4] -= d;
+            }
+        }
+        od_frag<f32x3_t> fp[NQT][2];
+#pragma unroll
+        for (int qi = 0; qi < NQT; qi++) {
+            f32x4 ps = (f32x4)(0.f);
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) {
+                f32x4 p;
+#pragma unroll
+                for (int r = 0; r < 4; r++) p[r] = od_exp2(e[qi][t4][r]);
+                ps += p;
+                od_frag_set4(fp[qi][t4 >> 1], t4 & 1, p[0], p[1], p[2], p[3]);
+            }
+            lrun[qi] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        }
+        // O^T += V^T P^T : V^T fragments by transpose reads of the row-major hi / lo planes
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                od_frag<bf16_t> vh, vl;
+                frag_cols<128, 128>(vh, st + 2 * PL, st + 2 * PL, dt * 16, x, u, g);
+                frag_cols<128, 128>(vl, st + 3 * PL, st + 3 * PL, dt * 16, x, u, g);
+                od_frag<f32x3_t> fv;
+                fv.hi = vh.v; fv.lo = vl.v;
+#pragma unroll
+                for (int qi = 0; qi < NQT; qi++) oacc[qi][dt] = od_mma(fv, fp[qi][u], oacc[qi][dt]);
+            }
+        if (kt + 1 < nkt) lstore(smem + ((kt + 1) & 1) * STAGE);
+        __syncthreads();
+    };
+    const int nfull = L / 64;
+    if (nfull > 0) tile(0, std::false_type{}, std::true_type{});
+    else tile(0, std::true_type{}, std::true_type{});
+    for (int kt = 1; kt < nfull; kt++) tile(kt, std::false_type{}, std::false_type{});
+    if (nfull > 0 && nfull < nkt) tile(nfull, std::true_type{}, std::false_type{});
+#pragma unroll
+    for (int qi = 0; qi < NQT; qi++) {
+        float l = lrun[qi];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.f / l;
+        const int row = q0 + qi * 16 + x;
+        if (row < L) {
+            float* orow = o + ((size_t)b * L + row) * ldo + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+                st4(orow + dt * 16 + 4 * g, oacc[qi][dt][0] * inv, oacc[qi][dt][1] * inv, oacc[qi][dt][2] * inv, oacc[qi][dt][3] * inv);
+            if (g == 0) lse[((size_t)b * H + h) * L + row] = (mref[qi] * c + log2f(l)) * LN2;
+        }
+    }
+}
+
 // ======================================================================== forward, bf16, head_dim 64, 32x32x16 MFMA
 // Round-2 rewrite of the bf16 hot path, driven by the issue-model probe (tools/probes/issue_model.hip ->
 // profiles/r02a_issue_model.txt): a gfx950 SIMD issues ONE instruction per ~4.2-4.5 cycles whatever its kind and however
@@ -881,6 +1065,16 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
         const int grid = attn_grid((L + NW * NQB * 32 - 1) / (NW * NQB * 32), B * H);
         OD_LAUNCH_DYN((flash_fwd32_kernel<NW, NQB, PRE>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq,
                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L, scale);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
+#ifndef OD_FWD_X3P
+#define OD_FWD_X3P 1      // fp32-as-3-x-bf16, head_dim 64: the kernel that splits K / V once per tile at staging time (0 = the generic kernel, for A/B)
+#endif
+    if constexpr (OD_FWD_X3P && std::is_same<T, f32x3_t>::value && HD == 64) {
+        const int grid = attn_grid((L + 4 * 32 - 1) / (4 * 32), B * H);
+        OD_LAUNCH_DYN((flash_fwd_x3p_kernel<4, PRE, 2>), dim3(grid), dim3(256), (2 * 4 * 64 * 128), st, (const float*)q, ldq, (const float*)k, ldk,
+                      (const float*)v, ldv, (float*)o, ldo, lse, B, H, L, scale);
         OD_CHECK_LAUNCH();
         return 0;
     }
