@@ -156,26 +156,47 @@ def load_sampler_parity():
 
 
 class PowerSampler:
-    """Samples `rocm-smi` (board power, shader clock) from a host thread while a region runs, so that the line says what box / what
-    throttle state the number was taken in.  Every field is None where rocm-smi is absent or unreadable (an ordinary user on the GPU
-    box may read it; nothing here changes a GPU setting)."""
+    """Samples the GPU's hwmon files (board power, shader clock) from a host thread while a region runs, so that the line says what box / what
+    throttle state the number was taken in.  Plain reads of /sys/class/drm/card*/device/hwmon/*/{power1_input,freq1_input,power1_cap} — no child
+    process (a `rocm-smi` child is an exec from a GPU-initialised process: refused under rocprofv3) and nothing that changes a GPU setting.
+    Every field is None where the files are absent or unreadable."""
 
-    SMI = "/opt/rocm/bin/rocm-smi"
-
-    def __init__(self, device_index=0, period_s=0.25):
+    def __init__(self, device_index=0, period_s=0.1):
         import threading
-        self.dev, self.period = device_index, period_s
+        self.period = period_s
+        self.dir = self._hwmon_of(device_index)
         self.samples, self._stop, self._thr = [], threading.Event(), None
 
-    def _read(self):
-        import re, subprocess
+    @staticmethod
+    def _hwmon_of(device_index):
+        import glob
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+        cands = [os.path.dirname(c) for c in cands]
+        if not cands:
+            return None
+        if len(cands) == 1:
+            return cands[0]
+        try:                                   # several GPUs visible: match the PCI address torch reports for this device
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for c in cands:
+                if want in os.path.realpath(os.path.join(c, "..", "..")):
+                    return c
+        except Exception:
+            pass
+        return cands[device_index] if device_index < len(cands) else None
+
+    def _num(self, name):
         try:
-            o = subprocess.run([self.SMI, "-d", str(self.dev), "-P", "-c"], capture_output=True, text=True, timeout=5).stdout
+            return float(open(os.path.join(self.dir, name)).read().strip())
         except Exception:
             return None
-        p = re.search(r"Power \(W\):\s*([\d.]+)", o)
-        c = re.search(r"sclk clock level:?\s*\d*:?\s*\((\d+)Mhz\)", o)
-        return (float(p.group(1)) if p else None, float(c.group(1)) if c else None)
+
+    def _read(self):
+        if self.dir is None:
+            return None
+        p, c = self._num("power1_input"), self._num("freq1_input")
+        return (p / 1e6 if p is not None else None, c / 1e6 if c is not None else None)
 
     def __enter__(self):
         import threading
@@ -195,20 +216,15 @@ class PowerSampler:
         self._thr.join(timeout=10)
 
     def cap_w(self):
-        import re, subprocess
-        try:
-            o = subprocess.run([self.SMI, "-d", str(self.dev), "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
-            m = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", o)
-            return float(m.group(1)) if m else None
-        except Exception:
-            return None
+        v = self._num("power1_cap") if self.dir is not None else None
+        return v / 1e6 if v is not None else None
 
     def summary(self):
         pw = [p for p, _ in self.samples if p is not None]
         ck = [c for _, c in self.samples if c is not None]
         return {"power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "clk_mhz_mean": round(sum(ck) / len(ck), 1) if ck else None,
                 "power_cap_w": self.cap_w(), "samples": len(self.samples),
-                "source": "rocm-smi -P -c sampled from a host thread over the timed region (the sampled sclk is the instantaneous level, not a cycle average)"}
+                "source": "hwmon power1_input / freq1_input of the GPU, sampled from a host thread over the timed region (instantaneous readings, not cycle averages)"}
 
 
 def mfma_calibration(device, seconds=2.0):
@@ -274,6 +290,10 @@ def roofline_of_dominant_kernel(tr, B, L):
                                    "od_flash_attn_bwd (attention backward of one layer: delta, then dK/dV and dQ on two streams)"),
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "traffic_note": ("fabric-side bytes of the call (L2 misses + write-through stores).  The operands are ~4.3 GB (q, k, v, o, dO read once; dq, dk, dv written once); "
+                         "the rest is the dQ chain: a running fp32 tile of 16 KB per query tile handed key block -> key block, "
+                         f"2 x 16 KB x {B * H * ((L + 63) // 64) * (((L + 191) // 192) - 1) / 1e6:.2f} M hand-offs through an L2 that writes every store through (DESIGN.md section 3, round 4)"
+                         if fused else None),
         "ms_per_launch": round(t_bwd * 1e3, 3),
         "flops_counted": f"algorithmic: {BWD_PASSES_ALGORITHMIC} passes x 2*B*H*L^2*hd",
         "mfma_passes_executed": executed,

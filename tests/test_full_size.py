@@ -98,6 +98,78 @@ def test_attention_backward_vs_autograd_full_length(dev, L):
         assert rel(dv.float(), vr.grad) < tol and rel(dk.float(), kr.grad) < 1.5 * tol and rel(dq.float(), qr.grad) < 1.5 * tol
 
 
+@pytest.mark.parametrize("L,BH", [(8192, (2, 5)), (8191, (1, 3)), (32768, (1, 2))])      # configs[1], a ragged length, configs[4]
+def test_fused_attention_backward_full_length(dev, L, BH):
+    """od_flash_attn_bwd_fused at the BASELINE sequence lengths (43 / 43 / 171 key blocks chained per (batch, head); B*H not a multiple of the eight
+    queues), bf16: one (b, h) against torch autograd on dense L x L scores, everything against the two-kernel backward (dK / dV bit for bit: same tiles,
+    same order), and bit-identical dq on a second call."""
+    from osu_dreamer_amd import ops
+    B, H = BH
+    hd, M, dh = 64, B * L, H * 64
+    bf = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(7)
+    q, k, v, do = (torch.randn(M, dh, device=dev, generator=g).to(bf) for _ in range(4))
+    sc = 1 / math.sqrt(hd)
+    o = torch.empty(M, dh, dtype=bf, device=dev)
+    lse, delta = torch.empty(B, H, L, device=dev), torch.empty(B, H, L, device=dev)
+    ops.flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, sc)
+    dq7, dk7, dv7 = (torch.empty(M, dh, dtype=bf, device=dev) for _ in range(3))
+    ops.flash_attn_bwd(q, k, v, o, do, lse, delta, dq7, dk7, dv7, B, H, L, hd, sc)
+    ws = ops.FusedAttnBwdWorkspace(B, H, L, dev)
+    outs = []
+    for _ in range(2):
+        dq, dk, dv = (torch.full((M, dh), float("nan"), dtype=bf, device=dev) for _ in range(3))
+        ops.flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, sc, ws)
+        outs.append((dq, dk, dv))
+    assert ws.status() == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    dq, dk, dv = outs[0]
+    assert torch.equal(dk, dk7) and torch.equal(dv, dv7)
+    assert rel(dq.float(), dq7.float()) < 2e-3
+    b, h = B - 1, H - 1                                                   # the last (batch, head): the tail of a queue
+    sl = (slice(b * L, (b + 1) * L), slice(h * hd, (h + 1) * hd))
+    qr, kr, vr = (t[sl].float().clone().requires_grad_() for t in (q, k, v))
+    ref = torch.softmax(qr @ kr.t() * sc, -1) @ vr
+    ref.backward(do[sl].float())
+    assert rel(dq[sl].float(), qr.grad) < 4e-2 and rel(dk[sl].float(), kr.grad) < 4e-2 and rel(dv[sl].float(), vr.grad) < 2.5e-2
+
+
+def test_fused_attention_backward_under_uneven_load(dev):
+    """The chain's hand-offs with the chip busy and uneven: a second stream hammers the memory system (large copies and fills of varying size)
+    while the fused backward runs, five times over — every result bit-identical to the quiet run, every job processed.  (The failure this
+    guards against was timing-dependent: stale polls of a line that is being rewritten)"""
+    from osu_dreamer_amd import ops
+    B, H, L, hd = 4, 16, 8192, 64
+    M, dh = B * L, H * hd
+    bf = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(9)
+    q, k, v, do = (torch.randn(M, dh, device=dev, generator=g).to(bf) for _ in range(4))
+    sc = 1 / math.sqrt(hd)
+    o = torch.empty(M, dh, dtype=bf, device=dev)
+    lse = torch.empty(B, H, L, device=dev)
+    ops.flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, sc)
+    ws = ops.FusedAttnBwdWorkspace(B, H, L, dev)
+
+    def run():
+        dq, dk, dv = (torch.zeros(M, dh, dtype=bf, device=dev) for _ in range(3))
+        ops.flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, sc, ws)
+        return dq, dk, dv
+    quiet = run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev)
+    big = [torch.empty(n, dtype=torch.float32, device=dev) for n in (1 << 28, 3 << 26, 1 << 24)]
+    for rep in range(5):
+        with torch.cuda.stream(side):
+            for i in range(6):
+                big[(rep + i) % 3].fill_(float(i))
+                big[(rep + i + 1) % 3][: 1 << 24].copy_(big[(rep + i) % 3][: 1 << 24])
+        got = run()
+        torch.cuda.synchronize()
+        for a, b_ in zip(got, quiet):
+            assert torch.equal(a, b_), f"rep {rep}"
+    assert ws.status() == 0
+
+
 @pytest.mark.parametrize("M", [16 * 8192, 32 * 8192])      # 32 x 8192 = 262,144 rows: the bench's own M (its split counts, its XCD tile order)
 @pytest.mark.parametrize("N,K", [(3072, 512), (512, 1024), (2816, 512), (512, 1408), (512, 3072)])
 def test_gemm_bench_shapes_vs_torch(dev, N, K, M):

@@ -543,7 +543,7 @@ def test_flash_attention(dev, dtype, B, H, L, hd):
 
 
 @pytest.mark.parametrize("pre", [False, True])
-@pytest.mark.parametrize("B,H,L", [(2, 2, 75), (1, 3, 200), (2, 1, 64), (1, 9, 450), (3, 1, 192), (1, 2, 600)])
+@pytest.mark.parametrize("B,H,L", [(2, 2, 75), (1, 3, 200), (2, 1, 64), (1, 9, 450), (3, 1, 192), (1, 2, 600), (1, 1, 65), (1, 11, 193), (2, 1, 385)])
 def test_flash_attn_bwd_fused(dev, B, H, L, pre):
     """od_flash_attn_bwd_fused (5 MFMA passes, dQ through the key-block chain; bf16, head_dim 64) against dense fp32 autograd and against
     od_flash_attn_bwd.  Lengths cover one and several key blocks (192 keys each), ragged key blocks and query tiles, more (batch, head)
