@@ -80,6 +80,7 @@ class DenoiserEngine:
         self.generation = 0
         self._attn_aux = None
         self._attn_ws = None          # workspace of the fused (5-pass) attention backward, per (B, H, L)
+        self._attn_ws_checked = False
 
     # ------------------------------------------------------------------ parameters
     def P(self, name: str) -> torch.Tensor:
@@ -302,6 +303,7 @@ class DenoiserEngine:
         if self.fused_attn_bwd():
             if self._attn_ws is None or self._attn_ws.shape != (self.B, self.H, self.L) or self._attn_ws.buf.device != qk.device:
                 self._attn_ws = ops.FusedAttnBwdWorkspace(self.B, self.H, self.L, qk.device)
+                self._attn_ws_checked = False
             ops.flash_attn_bwd_fused(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:],
                                      self.B, self.H, self.L, self.hd, scale, self._attn_ws, q_prescaled=True)
         else:
@@ -427,3 +429,10 @@ class DenoiserEngine:
                              self.G("proj_style.0.bias"), None, False, OD_ACT_SILU)
         if reducer is not None:
             reducer.segment_done("head")
+        # The fused attention backward draws its jobs from one queue per XCD and needs every XCD to run at least one of its workgroups (observed
+        # on every launch so far: block b runs on XCD b % 8).  Its workspace keeps a sticky error word for the case that one did not; read it
+        # once, after the first backward of a plan (one device synchronisation), and refuse to train on silently incomplete gradients.
+        if self._attn_ws is not None and not self._attn_ws_checked:
+            self._attn_ws_checked = True
+            if self._attn_ws.status() != 0:
+                raise RuntimeError("od_flash_attn_bwd_fused left jobs unprocessed (an XCD without workgroups); set OD_ATTN_BWD_FUSED=0")
