@@ -33,6 +33,10 @@ constexpr int FB_KB = 4 * FB_NK * 16;             // keys per workgroup (192)
 constexpr int FB_TILE = 64 * 128;                 // one 64-row x 64-feature bf16 tile
 constexpr int FB_STAGE = 2 * FB_TILE + 512;       // Q, dO, (-lse', -delta)
 constexpr int FB_DS = FB_KB * 128;                // dS of one tile: [192 keys][64 queries] bf16
+#ifndef FB_NSLOTS
+#define FB_NSLOTS 4
+#endif
+constexpr int FB_SLOTS = FB_NSLOTS;                          // (batch, head)s per XCD whose running tiles exist at a time (two are in flight; the buffer is reused)
 constexpr int FB_RUN_TILE = 4 * 4 * 64 * 4;          // floats of one (batch-head, query tile) of the running buffer: 4 waves x 4 pieces x 64 lanes x 4
 constexpr int FB_SMEM = 2 * FB_STAGE + 2 * FB_DS + 16;
 
@@ -364,17 +368,25 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             f32x4 acc[4][4], rb[4];
             unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};       // FB_PROF cycle counters
             const size_t tile_f = FB_RUN_TILE;                           // floats of one (bh, tile): [hh][G][lane][4]
-            const bool first = kblk == 0, last = kblk == nkb - 1;
-            // Tags.  A slot of the running buffer is written nkb - 1 times per launch, always in the same order; number those writes through the
-            // life of the workspace: c = 1 + launches * (nkb - 1) + key block (a zero-filled slot is "write 0").  Every 16-byte piece (one lane of
-            // one load / store instruction: the unit the memory system moves) carries c mod 4096, three bits in the lowest mantissa bits of each
-            // of its four dwords (2^-20 relative per hop: far below the bf16 result's own rounding).  A piece is accepted only if it carries the
-            // predecessor's number: the consumer polls a line that is being rewritten, and what comes back is not always the newest version
-            // (measured: under a burst of L2 evictions a poll can return the line as it was two or four writes ago, whole 128-byte lines at a
-            // time) — every piece has to prove which write it belongs to.  (Three values + a 32-bit number per piece was built too: exact
-            // values, a third of the vector-ALU work, but six pieces instead of four per tile and wave — and this path is bound by the bytes it
-            // moves: 25.2 ms per call against 23.9, profiles/r04o_tagword.txt.)
-            const unsigned id_mine = (1u + (unsigned)calls * (unsigned)(nkb - 1) + (unsigned)kblk) & 0xfffu, id_pred = (id_mine - 1u) & 0xfffu;
+            const bool last = kblk == nkb - 1;
+            // Tags.  The running tiles of a (batch, head) live in one of FB_SLOTS slots of its XCD — slot (bh / 8) % FB_SLOTS, reused by every
+            // FB_SLOTS-th (batch, head) of that XCD's queue: 64 MB instead of a tile per (batch, head, query tile), small enough to stay in the
+            // Infinity Cache.  EVERY key block reads the tile and writes it back (the first ignores what it reads, the last writes a bare marker
+            // beside dQ), always in the same order, so the writes of a slot can be numbered through the life of the workspace:
+            //     c = 1 + (launches * G + generation) * nkb + key block        (G = generations of this slot per launch; a zero-filled slot is "write 0")
+            // and a key block proceeds only when the tile carries c - 1: its predecessor's write — or, for the first key block, the LAST block's marker
+            // of the slot's previous user, i.e. that user has read what is about to be overwritten.  Every 16-byte piece (one lane of one load /
+            // store instruction: the unit the memory system moves) carries c mod 4096, three bits in the lowest mantissa bits of each of its four
+            // dwords (2^-20 relative per hop: far below the bf16 result's own rounding).  A piece is accepted only with exactly that number: the
+            // consumer polls a line that is being rewritten, and what comes back is not always the newest version (measured: under a burst of L2
+            // evictions a poll can return the line as it was two or four writes ago, whole 128-byte lines at a time) — every piece has to prove
+            // which write it belongs to.  (Three values + a 32-bit number per piece was built too: exact values, a third of the vector-ALU work,
+            // but six pieces instead of four per tile and wave — and this path is bound by the bytes it moves: 25.2 ms per call against 23.9,
+            // profiles/r04o_tagword.txt.)
+            const int bhq = bh >> 3, slot = bhq % FB_SLOTS, gen = bhq / FB_SLOTS;
+            const int nbhq_x = (BH - xcc + 7) >> 3;                      // (batch, head)s of this XCD's queue
+            const int gens = (nbhq_x - slot + FB_SLOTS - 1) / FB_SLOTS;  // ... that use this slot
+            const unsigned id_mine = (unsigned)od_uniform((int)((1u + ((unsigned)calls * (unsigned)gens + (unsigned)gen) * (unsigned)nkb + (unsigned)kblk) & 0xfffu)), id_pred = (id_mine - 1u) & 0xfffu;
             auto tag_of = [](unsigned id, int r) FB_INLINE -> unsigned { return (id >> (3 * r)) & 7u; };
             // dQ^T share of tile tau from the dS image it was published in.  The transpose reads of slab s + 1 are issued before the MFMAs of slab s:
             // read -> wait -> MFMA one fragment at a time (what the plain loop compiles to) costs an LDS round trip per MFMA, ~3000 cycles per
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            const size_t rbh = (size_t)bh;
+            const size_t rbh = (size_t)od_uniform(xcc * FB_SLOTS + slot);
             const fb_rsrc_t run_rs = fb_make_rsrc(run + rbh * nqt * tile_f, (unsigned)((size_t)nqt * tile_f * 4));
             const unsigned run_vo = (unsigned)((hh * 1024 + lane * 4) * 4);
             float* const run_st = run + rbh * nqt * tile_f + (size_t)hh * 1024 + (size_t)lane * 4;
@@ -421,12 +433,10 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                 return !__any((bad & 7u) != 0);
             };
             auto chain_commit = [&](int tau, f32x4 (&a)[4]) FB_INLINE {            // running sum (rb, tags verified) + this block's share -> next block, or the finished dQ
-                if (!first) {
 #pragma unroll
-                    for (int G = 0; G < 4; G++)
+                for (int G = 0; G < 4; G++)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) a[G][r] += fb_u2f(fb_f2u(rb[G][r]) & ~7u);
-                }
+                    for (int r = 0; r < 4; r++) a[G][r] += fb_u2f(fb_f2u(rb[G][r]) & ~7u);      // (the first key block adds the marker tile's zeros)
                 if (!last) {
 #pragma unroll
                     for (int G = 0; G < 4; G++) {
@@ -446,6 +456,11 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                             *(u32x2*)(dq + ((size_t)b * L + qrow) * lddq + h * 64 + 16 * hh + 4 * g) = w;
                         }
                     }
+                    f32x4 t;                                             // the marker "this tile has been read" (tags on zeros): the slot's next user waits for it
+#pragma unroll
+                    for (int r = 0; r < 4; r++) t[r] = fb_u2f(tag_of(id_mine, r));
+#pragma unroll
+                    for (int G = 0; G < 4; G++) *(f32x4*)(run_st + (size_t)tau * tile_f + G * 256) = t;
                 }
             };
             auto commit_dyn = [&](int tau) FB_INLINE {                             // the share of tile tau sits in ring slot tau & 3 (a wave-uniform switch)
@@ -464,28 +479,25 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             int done = 0;
             bool inflight = false;
             auto chain_request = [&](int produced) FB_INLINE {                     // top of an iteration: tiles < produced have their share in the ring
-                if ((FB_X & 1) || first || inflight || done >= produced) return;
+                if ((FB_X & 1) || inflight || done >= produced) return;
                 chain_load(done, rb);
                 inflight = true;
             };
             auto chain_try = [&](int produced, int must_reach) FB_INLINE {         // end of an iteration (all loads landed); must_reach: ring capacity
                 if (FB_X & 1) { done = produced; return; }
                 if (done < produced) {
-                    if (first) { commit_dyn(done); done++; }
-                    else if (inflight) {
+                    if (inflight) {
                         inflight = false;
                         if (tags_good(rb)) { commit_dyn(done); done++; }
                         else if (FB_PROF) ph[5]++;
                     }
                 }
                 while (done < must_reach) {                              // the ring is full (or the job ends): now it has to be waited for
-                    if (!first) {
-                        for (;;) {
-                            FB_COMPILER_FENCE();                         // every reload is a NEW read of memory another CU is writing
-                            chain_load(done, rb);
-                            if (tags_good(rb)) break;
-                            fb_sleep();
-                        }
+                    for (;;) {
+                        FB_COMPILER_FENCE();                             // every reload is a NEW read of memory another CU is writing
+                        chain_load(done, rb);
+                        if (tags_good(rb)) break;
+                        fb_sleep();
                     }
                     commit_dyn(done);
                     done++;
@@ -578,7 +590,8 @@ inline FbLayout fb_layout(int B, int H, int L) {
     l.nl = fb_align(sizeof(FbSync));
     l.nd = l.nl + fb_align(BH * L * sizeof(float));
     l.run = l.nd + fb_align(BH * L * sizeof(float));
-    l.total = l.run + fb_align(BH * nqt * FB_RUN_TILE * sizeof(float));
+    (void)BH;
+    l.total = l.run + fb_align((size_t)8 * FB_SLOTS * nqt * FB_RUN_TILE * sizeof(float));
     return l;
 }
 

@@ -543,11 +543,12 @@ def test_flash_attention(dev, dtype, B, H, L, hd):
 
 
 @pytest.mark.parametrize("pre", [False, True])
-@pytest.mark.parametrize("B,H,L", [(2, 2, 75), (1, 3, 200), (2, 1, 64), (1, 9, 450), (3, 1, 192), (1, 2, 600), (1, 1, 65), (1, 11, 193), (2, 1, 385)])
+@pytest.mark.parametrize("B,H,L", [(2, 2, 75), (1, 3, 200), (2, 1, 64), (1, 9, 450), (3, 1, 192), (1, 2, 600), (1, 1, 65), (1, 11, 193), (2, 1, 385), (5, 7, 200), (1, 41, 250)])
 def test_flash_attn_bwd_fused(dev, B, H, L, pre):
     """od_flash_attn_bwd_fused (5 MFMA passes, dQ through the key-block chain; bf16, head_dim 64) against dense fp32 autograd and against
     od_flash_attn_bwd.  Lengths cover one and several key blocks (192 keys each), ragged key blocks and query tiles, more (batch, head)
-    pairs than XCD queues, and a second call on the same workspace (the control block and flags must be left re-armed)."""
+    pairs than XCD queues, more than 8 x FB_SLOTS of them (the running-tile slots are reused within a launch, with ragged queues), and a second
+    call on the same workspace (the control block, flags and write numbers must be left re-armed)."""
     hd, dtype = 64, torch.bfloat16
     g = torch.Generator().manual_seed(31)
     M, dh = B * L, H * hd
