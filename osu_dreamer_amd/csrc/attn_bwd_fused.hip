@@ -40,6 +40,15 @@ constexpr int FB_SLOTS = FB_NSLOTS;                          // (batch, head)s p
 constexpr int FB_RUN_TILE = 4 * 4 * 64 * 4;          // floats of one (batch-head, query tile) of the running buffer: 4 waves x 4 pieces x 64 lanes x 4
 constexpr int FB_SMEM = 2 * FB_STAGE + 2 * FB_DS + 16;
 
+#ifndef FB_ORDER
+#define FB_ORDER 3     // how a query wave orders its vector-memory work inside an iteration (1, 2: measured alternatives, profiles/r04ac)
+#endif
+#ifndef FB_REQ
+#define FB_REQ 2       // the slab of the dQ product after which the running tile is requested
+#endif
+#ifndef FB_SPLIT
+#define FB_SPLIT 0     // how the four query waves split the dQ product of a tile (see there; 1, 2: measured alternatives, profiles/r04ae)
+#endif
 #ifndef FB_X
 #define FB_X 0        // timing experiments only (wrong dq): bit 0 = no chain traffic, bit 1 = no dQ products, bit 2 = no dS publication, bit 3 = no running-tile loads,
                       // bit 4 = no running-tile stores, bit 5 = tags not checked
@@ -174,6 +183,11 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
     if (threadIdx.x == 0) s_job[0] = fb_atomic_inc(&sync->head[xcc]);
     __syncthreads();
     int job = od_uniform(s_job[0]), jpar = 0;
+    // One job loop PER ROLE (the same code, instantiated twice, the role branch outside): a role's loop-invariant values — LDS offsets, lane
+    // constants: a dozen registers each — are then live in its own loop only.  With the branch inside a common loop they were hoisted out of it
+    // and stayed live through BOTH roles' inner loops, which are each at the register limit.
+    auto run_jobs = [&](auto role_) FB_INLINE {
+    constexpr bool KEY_ROLE = decltype(role_)::value;
     for (;; jpar ^= 1) {
         if (job >= jobs_per_xcd) break;
         my_jobs++;
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
 #ifndef FB_PRIO
 #define FB_PRIO 0         // s_setprio of the key waves (the query waves stay at 0)
 #endif
-        if (key_wave) {
+        if constexpr (KEY_ROLE) {
             // =================================================================== key waves
             if (FB_PRIO) __builtin_amdgcn_s_setprio(FB_PRIO);
             const int key0 = kblk * KB + wave * NK * 16;
@@ -314,16 +328,30 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             }
         } else {
             // =================================================================== query waves
-            const int hh = wave - 4;                        // feature slice 16 hh .. 16 hh + 15
-            // K^T slice, A operand of slab s (32 keys): row = feature 16 hh + x, k-slot (g, j) = key 32 s + 8 g + j of the block
-            od_frag<bf16_t> fkt[6];
+            const int hh = wave - 4;
+            // The dQ product of a tile, dQ^T[64 features x 64 queries] = K^T[64 x 192 keys] dS[192 x 64], is split by FEATURES: wave h owns feature tile h
+            // (K^T slice in 24 registers, gathered once per job) for all four 16-query groups, and reads the whole dS image (48 transpose reads per
+            // tile).  A split by QUERIES reads a quarter of the image (12 reads; the whole K^T of the block in 96 registers) and is SLOWER, 24.8 ms per
+            // call against 22.6 (two features x two groups: 23.1): its four MFMAs per slab come back to back and hold up the key wave on the same
+            // SIMD, which is the pace of the workgroup; the LDS reads in between were spacing them out for free.  A operand of feature tile j, slab s
+            // (32 keys): row = feature 16 j + x, k-slot (g, i) = key 32 s + 8 g + i of the block.
+            // (FB_SPLIT: 0 = by features — wave h owns feature tile h for all four query groups —, 1 = by queries, 2 = two feature tiles x two groups)
+            constexpr int NJ = FB_SPLIT == 0 ? 1 : FB_SPLIT == 1 ? 4 : 2, NG = 4 / NJ;     // feature tiles / query groups of a wave; accumulator a = (ji, gi)
+            auto ji_of = [](int a) FB_INLINE { return FB_SPLIT == 0 ? 0 : FB_SPLIT == 1 ? a : a >> 1; };
+            auto gi_of = [](int a) FB_INLINE { return FB_SPLIT == 0 ? a : FB_SPLIT == 1 ? 0 : a & 1; };
+            const int j0 = FB_SPLIT == 0 ? hh : FB_SPLIT == 1 ? 0 : 2 * (hh & 1), G0 = FB_SPLIT == 0 ? 0 : FB_SPLIT == 1 ? hh : 2 * (hh >> 1);
+            od_frag<bf16_t> fkt[NJ][6];
 #pragma unroll
             for (int s = 0; s < 6; s++) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {                                // clamped address + select: 48 independent loads, no branches
-                    const int key = kblk * KB + 32 * s + 8 * g + j;
-                    const short kv = (short)kb_[(size_t)(key < L ? key : L - 1) * ldk + 16 * hh + x];
-                    fkt[s].v[j] = key < L ? kv : (short)0;
+                for (int i = 0; i < 8; i++) {                                // clamped address + select: independent loads, no branches
+                    const int key = kblk * KB + 32 * s + 8 * g + i;
+                    const bf16_t* kr = kb_ + (size_t)(key < L ? key : L - 1) * ldk + 16 * j0 + x;
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) {
+                        const short kv = (short)kr[16 * j];
+                        fkt[j][s].v[i] = key < L ? kv : (short)0;
+                    }
                 }
             }
             // Q / dO tile streaming: piece = 8 rows x 128 B; this wave moves pieces hh and hh + 4 of both tiles; waves 0 / 1 also move the
@@ -334,30 +362,36 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             const int prow = lane >> 3, pslot = (lane & 7) ^ prow;          // tile_off<128>: slot ^ (row & 7), row & 7 = lane >> 3
             const unsigned vq = (unsigned)((hh * 8 + prow) * ldq * 2 + pslot * 16), vo = (unsigned)((hh * 8 + prow) * lddo * 2 + pslot * 16);
             const unsigned smem_a = od_lds_addr(smem);
-            auto dma = [&](int qt) FB_INLINE {
-                qt = od_uniform(qt);
+            // the tile DMA in five single-instruction pieces (0, 1: Q rows 0..31 / 32..63; 2, 3: dO; 4: the tile's -lse / -delta rows): a wave's vector-memory
+            // instruction issues only when the CU's address pipeline (64 bytes per clock for the DMA, the running-tile loads AND stores: ~1000 clocks
+            // per tile) takes it, so the pieces go out one at a time between the slabs of the dQ product instead of back to back in front of it
+            auto dma_piece = [&](int qt, int j) FB_INLINE {
                 const unsigned st = (unsigned)od_uniform((int)(smem_a + (unsigned)((qt & 1) * FB_STAGE) + (unsigned)hh * 1024u));     // this wave's piece
                 const unsigned qi = (unsigned)od_uniform(qt);
                 const unsigned sq = qi * 64u * (unsigned)ldq * 2u, so = qi * 64u * (unsigned)lddo * 2u;
-                od_buffer_lds16_at(rq, vq, sq, st);
-                od_buffer_lds16_at(rq, vq, sq + 32u * (unsigned)ldq * 2u, st + 4096);
-                od_buffer_lds16_at(ro, vo, so, st + FB_TILE);
-                od_buffer_lds16_at(ro, vo, so + 32u * (unsigned)lddo * 2u, st + FB_TILE + 4096);
-                if (hh < 2) od_buffer_lds4_at(rs, (unsigned)lane * 4u, qi * 256u, (unsigned)od_uniform((int)(st + 2 * FB_TILE - (unsigned)hh * 768u)));
+                if (j == 0) od_buffer_lds16_at(rq, vq, sq, st);
+                if (j == 1) od_buffer_lds16_at(rq, vq, sq + 32u * (unsigned)ldq * 2u, st + 4096);
+                if (j == 2) od_buffer_lds16_at(ro, vo, so, st + FB_TILE);
+                if (j == 3) od_buffer_lds16_at(ro, vo, so + 32u * (unsigned)lddo * 2u, st + FB_TILE + 4096);
+                if (j == 4 && hh < 2) od_buffer_lds4_at(rs, (unsigned)lane * 4u, qi * 256u, (unsigned)od_uniform((int)(st + 2 * FB_TILE - (unsigned)hh * 768u)));
+            };
+            auto dma = [&](int qt) FB_INLINE {
+                qt = od_uniform(qt);
+#pragma unroll
+                for (int j = 0; j < 5; j++) dma_piece(qt, j);
             };
             // lane-constant LDS offsets of the dS^T transpose-read chunks: query group G (16 columns = slots 2G, 2G+1), slab rows 8 g + (x >> 2) (+4)
-            int tr_off[4][2];
+            int tr_off[NG][2], qcol[NG];                                 // qcol: the query this lane's accumulator column stands for (the order the key waves packed them in)
 #pragma unroll
-            for (int G = 0; G < 4; G++)
+            for (int gi = 0; gi < NG; gi++) {
+                const int G = G0 + gi;
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const int row = 8 * g + (x >> 2) + 4 * e;           // + 32 s: bits 3.. of the row unchanged mod 16 -> same swizzle
-                    tr_off[G][e] = row * 128 + (((2 * G + ((x & 3) >> 1)) ^ fb_swz(row)) << 4) + (x & 1) * 8;
+                    tr_off[gi][e] = row * 128 + (((2 * G + ((x & 3) >> 1)) ^ fb_swz(row)) << 4) + (x & 1) * 8;
                 }
-            // the query this lane's accumulator column stands for, per group G (the order the key waves packed them in)
-            int qcol[4];
-#pragma unroll
-            for (int G = 0; G < 4; G++) qcol[G] = 16 * (2 * (G >> 1) + ((x >> 2) & 1)) + 4 * (2 * (G & 1) + (x >> 3)) + (x & 3);
+                qcol[gi] = 16 * (2 * (G >> 1) + ((x >> 2) & 1)) + 4 * (2 * (G & 1) + (x >> 3)) + (x & 3);
+            }
 
             // ---- chain pipeline.  Every dword of a running tile carries a 2-bit tag in its lowest mantissa bits that identifies its writer (below).  The consumer simply loads the tile and looks at the tags — no flag, no acknowledgement to wait for: a tile that is
             // not there yet (or half there) shows a wrong tag somewhere and is loaded again.  Per tile tau:
@@ -391,29 +425,31 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             // dQ^T share of tile tau from the dS image it was published in.  The transpose reads of slab s + 1 are issued before the MFMAs of slab s:
             // read -> wait -> MFMA one fragment at a time (what the plain loop compiles to) costs an LDS round trip per MFMA, ~3000 cycles per
             // tile, which made this wave — not the key wave beside it — the pace of the workgroup.
-            auto phase_b = [&](int tau, f32x4 (&a)[4]) FB_INLINE {
+            auto phase_b = [&](int tau, f32x4 (&a)[4], auto&& between) FB_INLINE {          // between(s): vector-memory work to issue after slab s
                 const unsigned char* dsb = smem + 2 * FB_STAGE + (tau & 1) * FB_DS;
-                s16x4 f[2][4][2];                                        // [buffer][G][half]
-                auto rd = [&](int s, s16x4 (&dst)[4][2]) FB_INLINE {               // the 8 transpose reads of slab s
+                s16x4 f[2][NG][2];                                       // [buffer][group][half]
+                auto rd = [&](int s, s16x4 (&dst)[NG][2]) FB_INLINE {              // the 2 NG transpose reads of slab s
 #pragma unroll
-                    for (int G = 0; G < 4; G++)
+                    for (int gi = 0; gi < NG; gi++)
 #pragma unroll
-                        for (int e = 0; e < 2; e++) dst[G][e] = od_lds_tr_read((const bf16_t*)(dsb + s * 4096 + tr_off[G][e]));
+                        for (int e = 0; e < 2; e++) dst[gi][e] = od_lds_tr_read((const bf16_t*)(dsb + s * 4096 + tr_off[gi][e]));
                 };
                 rd(0, f[0]);
 #pragma unroll
                 for (int s = 0; s < 6; s++) {
                     if (s + 1 < 6) rd(s + 1, f[(s + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);                   // keep the reads of the next slab ABOVE this slab's MFMAs
+                    od_frag<bf16_t> fb[NG];
 #pragma unroll
-                    for (int G = 0; G < 4; G++) {
-                        const s16x4 b0 = f[s & 1][G][0], b1 = f[s & 1][G][1];
-                        od_frag<bf16_t> fb;
-                        fb.v[0] = b0[0]; fb.v[1] = b0[1]; fb.v[2] = b0[2]; fb.v[3] = b0[3];
-                        fb.v[4] = b1[0]; fb.v[5] = b1[1]; fb.v[6] = b1[2]; fb.v[7] = b1[3];
-                        a[G] = od_mma(fkt[s], fb, s == 0 ? (f32x4)(0.f) : a[G]);
+                    for (int gi = 0; gi < NG; gi++) {
+                        const s16x4 b0 = f[s & 1][gi][0], b1 = f[s & 1][gi][1];
+                        fb[gi].v[0] = b0[0]; fb[gi].v[1] = b0[1]; fb[gi].v[2] = b0[2]; fb[gi].v[3] = b0[3];
+                        fb[gi].v[4] = b1[0]; fb[gi].v[5] = b1[1]; fb[gi].v[6] = b1[2]; fb[gi].v[7] = b1[3];
                     }
+#pragma unroll
+                    for (int G = 0; G < 4; G++) a[G] = od_mma(fkt[ji_of(G)][s], fb[gi_of(G)], s == 0 ? (f32x4)(0.f) : a[G]);
                     __builtin_amdgcn_sched_barrier(0);
+                    between(s);
                 }
             };
             const size_t rbh = (size_t)od_uniform(xcc * FB_SLOTS + slot);
@@ -448,12 +484,12 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                 } else {
 #pragma unroll
                     for (int G = 0; G < 4; G++) {
-                        const int qrow = tau * 64 + qcol[G];
+                        const int qrow = tau * 64 + qcol[gi_of(G)];
                         if (qrow < L) {
                             u32x2 w;
                             w[0] = od_pack_bf2(a[G][0] * out_scale, a[G][1] * out_scale);
                             w[1] = od_pack_bf2(a[G][2] * out_scale, a[G][3] * out_scale);
-                            *(u32x2*)(dq + ((size_t)b * L + qrow) * lddq + h * 64 + 16 * hh + 4 * g) = w;
+                            *(u32x2*)(dq + ((size_t)b * L + qrow) * lddq + h * 64 + 16 * (j0 + ji_of(G)) + 4 * g) = w;
                         }
                     }
                     f32x4 t;                                             // the marker "this tile has been read" (tags on zeros): the slot's next user waits for it
@@ -483,16 +519,19 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                 chain_load(done, rb);
                 inflight = true;
             };
-            auto chain_try = [&](int produced, int must_reach) FB_INLINE {         // end of an iteration (all loads landed); must_reach: ring capacity
-                if (FB_X & 1) { done = produced; return; }
+            // returns true when the vector-memory operations it issued are exactly one tile's four running-tile stores
+            auto chain_try = [&](int produced, int must_reach) FB_INLINE -> bool { // end of an iteration (the requested tile has landed); must_reach: ring capacity
+                if (FB_X & 1) { done = produced; return false; }
+                bool four = false;
                 if (done < produced) {
                     if (inflight) {
                         inflight = false;
-                        if (tags_good(rb)) { commit_dyn(done); done++; }
+                        if (tags_good(rb)) { commit_dyn(done); done++; four = !last; }
                         else if (FB_PROF) ph[5]++;
                     }
                 }
                 while (done < must_reach) {                              // the ring is full (or the job ends): now it has to be waited for
+                    four = false;
                     for (;;) {
                         FB_COMPILER_FENCE();                             // every reload is a NEW read of memory another CU is writing
                         chain_load(done, rb);
@@ -502,22 +541,38 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                     commit_dyn(done);
                     done++;
                 }
+                return four;
             };
             auto step = [&](int it, auto k_) FB_INLINE {
                 constexpr int K = decltype(k_)::value;                   // it & 3: the ring slot phase_b writes is compile-time
                 const unsigned long long t0 = FB_CLK();
-                if (it + 1 < nqt) dma(it + 1);
-                chain_request(it - 1);                                   // tiles 0 .. it-2 had their share in the ring when the last iteration ended
+                const int nxt = od_uniform(it + 1);
                 const unsigned long long t1 = FB_CLK();
-                if (!(FB_X & 2)) phase_b(it - 1, acc[(K + 3) & 3]);
+                if (!(FB_X & 2)) phase_b(it - 1, acc[(K + 3) & 3], [&](int s) FB_INLINE {
+#if FB_ORDER == 2
+                    if (s < 5) { if (nxt < nqt) dma_piece(nxt, s); }
+                    else chain_request(it - 1);
+#elif FB_ORDER == 1
+                    if (s == 0) chain_request(it - 1);
+                    else if (nxt < nqt) dma_piece(nxt, s - 1);
+#else
+                    // the DMA first (two pieces after slab 0, two after slab 1), then the running tile: the loads are compiler-visible, and the compiler
+                    // waits for a load with a count of the operations IT knows of — the asm DMA behind it would be waited for as well
+                    if (s < 2) { if (nxt < nqt) { dma_piece(nxt, 2 * s); dma_piece(nxt, 2 * s + 1); } }
+                    else if (s == 2) { if (nxt < nqt) dma_piece(nxt, 4); }
+                    if (s == FB_REQ) chain_request(it - 1);              // tiles 0 .. it-2 had their share in the ring when the last iteration ended
+#endif
+                });
+                else { chain_request(it - 1); if (nxt < nqt) dma(nxt); }
 #if FB_PROF && !defined(OD_EMU)
                 asm volatile("" : "+v"(acc[(K + 3) & 3][0]), "+v"(acc[(K + 3) & 3][1]), "+v"(acc[(K + 3) & 3][2]), "+v"(acc[(K + 3) & 3][3]));
 #endif
                 const unsigned long long t2 = FB_CLK();
                 FB_WAIT_ALL();                                           // the tile DMA and the requested running tile have landed
                 const unsigned long long t3 = FB_CLK();
-                chain_try(it, it - 3);                                   // the next share goes to slot it & 3, tile it - 4's: tiles < it - 3 must be gone
+                const bool four = chain_try(it, it - 3);                 // the next share goes to slot it & 3, tile it - 4's: tiles < it - 3 must be gone
                 const unsigned long long t4 = FB_CLK();
+                (void)four;
                 od_barrier_raw();                                        // bare: a fence here would wait for the stores just issued
                 if (FB_PROF) { const unsigned long long t5 = FB_CLK(); ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; }
             };
@@ -539,11 +594,12 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             if (it < nqt) { step(it, std::integral_constant<int, 3>{}); it++; }
             // the last tile's share (its dS was published before the final barrier), then whatever is still queued
             if (!(FB_X & 2)) {
+                auto nothing = [](int) FB_INLINE {};
                 switch ((nqt - 1) & 3) {
-                    case 0: phase_b(nqt - 1, acc[0]); break;
-                    case 1: phase_b(nqt - 1, acc[1]); break;
-                    case 2: phase_b(nqt - 1, acc[2]); break;
-                    default: phase_b(nqt - 1, acc[3]); break;
+                    case 0: phase_b(nqt - 1, acc[0], nothing); break;
+                    case 1: phase_b(nqt - 1, acc[1], nothing); break;
+                    case 2: phase_b(nqt - 1, acc[2], nothing); break;
+                    default: phase_b(nqt - 1, acc[3], nothing); break;
                 }
             }
             inflight = false;
@@ -553,6 +609,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
         }
         job = od_uniform(s_job[jpar ^ 1]);               // left there in front of the last tile's barrier
     }
+    };
+    if (key_wave) run_jobs(std::true_type{}); else run_jobs(std::false_type{});
     // ---- leave: the last workgroup out checks that every job ran and re-arms the control block for the next launch
     if (threadIdx.x == 0) {
         if (my_jobs) {

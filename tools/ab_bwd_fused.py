@@ -47,7 +47,7 @@ if __name__ == "__main__":
             for lib in args or [""]:
                 label, libpath, extra = parse(lib)
                 env = dict(os.environ, AB_CHILD="1", OSU_DREAMER_HIP_LIB=libpath, **extra)
-                out = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True, timeout=600)
+                out = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True, timeout=int(os.environ.get("AB_TIMEOUT", "120")))
                 line = [l for l in out.stdout.splitlines() if l.startswith("fused")]
                 for l in out.stdout.splitlines():
                     if l.startswith("prof"): print("      " + l)
