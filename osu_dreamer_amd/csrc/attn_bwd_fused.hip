@@ -285,16 +285,23 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                     // and, one per feature tile, the publication of dS: fragment u of key tile ki = queries {32u + 4g + r, 32u + 16 + 4g + r} of
                     // key row (wave, ki, x), one 16-byte slot.  A ds_write_b128 holds the LDS store path for ~13 cycles; three in a row in front
                     // of the MFMAs were fully exposed (1.5 ms per call), one between each group of six MFMAs hides behind them.
+                    // The transposed fragments of feature tile dt + 1 are read BEFORE the six MFMAs of tile dt: read -> wait -> MFMA per tile left the
+                    // LDS round trip of the transpose reads exposed eight times per query tile (this wave is alone with its MFMAs on the SIMD).
+                    od_frag<bf16_t> fot[2], fqt[2];
+                    frag_cols<128, 128>(fot[0], tO, tO, 0, x, u, g);
+                    frag_cols<128, 128>(fqt[0], tQ, tQ, 0, x, u, g);
 #pragma unroll
                     for (int dt = 0; dt < 4; dt++) {
+                        if (dt < 3) {
+                            frag_cols<128, 128>(fot[(dt + 1) & 1], tO, tO, (dt + 1) * 16, x, u, g);
+                            frag_cols<128, 128>(fqt[(dt + 1) & 1], tQ, tQ, (dt + 1) * 16, x, u, g);
+                        }
                         if (dt < NK && !(FB_X & 4)) *(s16x8*)(dsb + ((ds_off0 ^ (u * 64)) + dt * 2048)) = fds[dt].v;
-                        od_frag<bf16_t> fot, fqt;
-                        frag_cols<128, 128>(fot, tO, tO, dt * 16, x, u, g);
-                        frag_cols<128, 128>(fqt, tQ, tQ, dt * 16, x, u, g);
+                        __builtin_amdgcn_sched_barrier(0);               // the reads stay above this tile's MFMAs
 #pragma unroll
                         for (int ki = 0; ki < NK; ki++) {
-                            dvacc[ki][dt] = od_mma(fot, fp[ki], dvacc[ki][dt]);
-                            dkacc[ki][dt] = od_mma(fqt, fds[ki], dkacc[ki][dt]);
+                            dvacc[ki][dt] = od_mma(fot[dt & 1], fp[ki], dvacc[ki][dt]);
+                            dkacc[ki][dt] = od_mma(fqt[dt & 1], fds[ki], dkacc[ki][dt]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
