@@ -50,7 +50,7 @@ constexpr int FB_SMEM = 2 * FB_STAGE + 2 * FB_DS + 16;
 #define FB_SPLIT 0     // how the four query waves split the dQ product of a tile (see there; 1, 2: measured alternatives, profiles/r04ae)
 #endif
 #ifndef FB_X
-#define FB_X 0        // timing experiments only (wrong dq): bit 0 = no chain traffic, bit 1 = no dQ products, bit 2 = no dS publication, bit 3 = no running-tile loads,
+#define FB_X 0        // timing experiments only (wrong dq): bit 0 = no chain traffic, bit 1 = no dQ products, bit 2 = no dS publication, bit 8 = no exp2, bit 9 = no transposed Q / dO reads after the first, bit 10 = no row-major Q / dO reads after the first, bit 3 = no running-tile loads,
                       // bit 4 = no running-tile stores, bit 5 = tags not checked
 #endif
 
@@ -255,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                         od_frag<bf16_t> fqr[2], fdo[2];
 #pragma unroll
                         for (int s = 0; s < 2; s++) {
+                            if ((FB_X & 1024) && t4) { fqr[s] = fk[0][s]; fdo[s] = fv[0][s]; continue; }
                             frag_contig<128>(fqr[s], tQ, t4 * 16 + x, s * 32 + g * 8);
                             frag_contig<128>(fdo[s], tO, t4 * 16 + x, s * 32 + g * 8);
                         }
@@ -262,21 +263,23 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                         const f32x4 d4 = *(const f32x4*)(s_nd + t4 * 16 + 4 * g);
 #pragma unroll
                         for (int ki = 0; ki < NK; ki++) {
-                            f32x4 sa = l4, pa = d4;
+                            // (issuing the six chains of a 16-query tile step by step — no MFMA right behind the one it depends on — shortens this
+                            // loop by 0.7 % and lengthens the call by 1.5 %: the clumped MFMAs hold up the query wave; profiles/r04aj)
+                            f32x4 sa_ = l4, pa_ = d4;
 #pragma unroll
-                            for (int s = 0; s < 2; s++) { sa = od_mma(fqr[s], fk[ki][s], sa); pa = od_mma(fdo[s], fv[ki][s], pa); }
-                            f32x4 e = sa;
-                            if constexpr (!PRE) e = od_mul4s(sa, c);
+                            for (int s = 0; s < 2; s++) { sa_ = od_mma(fqr[s], fk[ki][s], sa_); pa_ = od_mma(fdo[s], fv[ki][s], pa_); }
+                            f32x4 e = sa_;
+                            if constexpr (!PRE) e = od_mul4s(sa_, c);
                             f32x4 p;
 #pragma unroll
-                            for (int r = 0; r < 4; r++) p[r] = od_exp2(e[r]);
+                            for (int r = 0; r < 4; r++) p[r] = (FB_X & 256) ? e[r] : od_exp2(e[r]);
                             if constexpr (MASKED) {
                                 const bool kvalid = key0 + ki * 16 + x < L;
 #pragma unroll
                                 for (int r = 0; r < 4; r++)
                                     if (!(kvalid && (qbase + t4 * 16 + 4 * g + r < L))) p[r] = 0.f;
                             }
-                            const f32x4 ds = od_mul4(p, pa);
+                            const f32x4 ds = od_mul4(p, pa_);
                             od_frag_set4(fp[ki], th, p[0], p[1], p[2], p[3]);
                             od_frag_set4(fds[ki], th, ds[0], ds[1], ds[2], ds[3]);
                         }
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                     frag_cols<128, 128>(fqt[0], tQ, tQ, 0, x, u, g);
 #pragma unroll
                     for (int dt = 0; dt < 4; dt++) {
-                        if (dt < 3) {
+                        if (dt < 3 && !(FB_X & 512)) {
                             frag_cols<128, 128>(fot[(dt + 1) & 1], tO, tO, (dt + 1) * 16, x, u, g);
                             frag_cols<128, 128>(fqt[(dt + 1) & 1], tQ, tQ, (dt + 1) * 16, x, u, g);
                         }
