@@ -157,9 +157,11 @@ int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const void* k, int 
  * bf16, head_dim 64 only (OD_ERR_UNSUPPORTED otherwise: call od_flash_attn_bwd).  Each workgroup owns 192 keys; its share of every 64-query
  * dQ tile is added to a running fp32 tile that travels key block -> key block through the XCD's L2 in a fixed order (deterministic, no
  * atomics on data), and the last key block writes dq.  `ws` is caller-owned device memory of od_flash_attn_bwd_fused_ws_bytes(...) bytes whose first
- * *zero_out bytes are zero before the first call (every call leaves them zero); one workspace serves any number of calls on one stream.
- * od_flash_attn_bwd_fused_status copies the workspace's sticky error word to the host (0 = every launch processed all of its jobs; it
- * synchronises the device: a test / debug aid).  replaces: autograd of attn.py:82. */
+ * *zero_out bytes are zero before the first call; one workspace serves any number of calls of ONE (B, H, L) on one stream (zero it again
+ * before a launch of another shape: the running tiles carry write numbers that continue from launch to launch).
+ * od_flash_attn_bwd_fused_status copies the workspace's sticky error word to the host (it synchronises the device: a test / debug aid):
+ * 0 = every launch processed all of its jobs, 1 = a launch left jobs unprocessed, 2 = a launch with another (B, H, L) than the workspace's
+ * earlier launches was refused (nothing was computed).  replaces: autograd of attn.py:82. */
 int od_flash_attn_bwd_fused_ws_bytes(int B, int H, int L, long* total_out, long* zero_out);
 int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
                             const void* dout, int lddo, const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,

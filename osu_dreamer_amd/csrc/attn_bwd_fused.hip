@@ -76,7 +76,8 @@ struct FbSync {
     int jobs_done;        // jobs processed (all XCDs)
     int err;              // sticky: 1 = a launch ended with unprocessed jobs (an XCD without workgroups)
     int calls;            // completed launches on this workspace: its number is in every running-tile tag
-    int pad[4];
+    int shape[3];         // B, H, L of the launches this workspace has served (0 = none yet): slot numbering and layout depend on them
+    int pad;
     unsigned long long prof[16];   // FB_PROF builds: cycle counts (see fb_prof_add)
 };
 
@@ -174,6 +175,15 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
     const bool key_wave = wave < 4;
     const int xcc = fb_xcc_id();
     const int calls = sync->calls;                     // launches completed on this workspace (the last workgroup out advances it)
+    // A workspace belongs to ONE (B, H, L): the write numbers in its running tiles continue from launch to launch, and a launch of another shape
+    // would wait for numbers that never come.  Every workgroup sees the same words here (they are written by the last workgroup to LEAVE a launch).
+    {
+        const int s0 = sync->shape[0], s1 = sync->shape[1], s2 = sync->shape[2];
+        if ((s0 | s1 | s2) != 0 && (s0 != B || s1 != H || s2 != L)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) fb_flag_store(&sync->err, 2);
+            return;
+        }
+    }
     const float c = scale * FB_LOG2E, out_scale = PRE ? FB_LN2 : scale;
     int my_jobs = 0;
 
@@ -644,6 +654,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             for (int i = 0; i < 8; i++) fb_flag_store(&sync->head[i], 0);
             fb_flag_store(&sync->jobs_done, 0);
             fb_flag_store(&sync->calls, sync->calls + 1);
+            fb_flag_store(&sync->shape[0], B); fb_flag_store(&sync->shape[1], H); fb_flag_store(&sync->shape[2], L);
             fb_flag_store(&sync->finished, 0);
         }
     }

@@ -278,9 +278,10 @@ class DenoiserEngine:
 
     def fused_attn_bwd(self) -> bool:
         """Whether the attention backward runs as od_flash_attn_bwd_fused: one kernel, the 5 algorithmic MFMA passes, dQ summed over key blocks by
-        the chain through the XCD's L2 (bf16, head_dim 64).  Default for L >= 6144: measured per layer at B*L = 262144 frames (profiles/r04v_misc.txt) —
-        L = 32768: 85.9 against 92.9 ms; 8192: 23.2 against 23.6-24.5; 4096: 12.6 / 12.6; 2048: 7.1 against 6.7 (short sequences run the chain in
-        lock step: a key block trails its predecessor by ~1.5 query tiles and consecutive key blocks start (L / 64) / (CUs per XCD) tiles apart);
+        the chain through the XCD's L2 (bf16, head_dim 64).  Default for L >= 2048, measured per call at batch 32 (profiles/r04ak_crossover.txt):
+        L = 2048: 1.64-1.70 against 1.71-1.88 ms; 4096: 5.7 against 6.3-6.4; 8192: 21.0-21.4 against 23.3-24.1; batch 8 x 32768: 81.0 against 94.0.
+        (Shorter sequences have not been measured: they run the chain in lock step — a key block trails its predecessor by ~1.5 query tiles and
+        consecutive key blocks start (L / 64) / (CUs per XCD) tiles apart.)
         OD_ATTN_BWD_FUSED=0 / 1 forces the two-kernel / the fused path."""
         import os
         if self.dtype != torch.bfloat16 or self.hd != 64:
@@ -288,7 +289,7 @@ class DenoiserEngine:
         env = os.environ.get("OD_ATTN_BWD_FUSED", "")
         if env in ("0", "1"):
             return env == "1"
-        return self.L >= 6144
+        return self.L >= 2048
 
     def attn_bwd_launch(self, i: int, dy: torch.Tensor, delta: torch.Tensor, dqkv: torch.Tensor, core_only: bool = False):
         """The backward of layer i's attention core + q / k norm + RoPE exactly as `backward` launches it: dy = gradient of the attention

@@ -588,6 +588,30 @@ def test_flash_attn_bwd_fused(dev, B, H, L, pre):
     assert rel_l2(dq.float(), dq7.float().cpu()) < 6e-3                                                     # fp32 chain vs in-register sum
 
 
+def test_flash_attn_bwd_fused_refuses_another_shape(dev):
+    """A workspace's running tiles carry write numbers that continue from launch to launch: a launch with another (B, H, L) must be refused
+    (status 2, nothing computed) instead of waiting for numbers that never come."""
+    from osu_dreamer_amd import _lib
+    hd, dtype, B, H, L = 64, torch.bfloat16, 1, 2, 200
+    g = torch.Generator().manual_seed(5)
+    M, dh = B * L, H * hd
+    q, k, v, do = (mk((M, dh), g, dev, dtype) for _ in range(4))
+    o = torch.zeros(M, dh, dtype=dtype, device=dev)
+    lse = torch.zeros(B, H, L, device=dev)
+    scale = 1 / math.sqrt(hd)
+    ops.flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale)
+    ws = ops.FusedAttnBwdWorkspace(B, H, L, dev)
+    dq, dk, dv = (torch.zeros(M, dh, dtype=dtype, device=dev) for _ in range(3))
+    ops.flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, scale, ws)
+    assert ws.status() == 0
+    with pytest.raises(AssertionError):
+        ops.flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L - 70, hd, scale, ws)      # the Python wrapper checks first
+    p, ld = ops._p, ops._ld
+    _lib.lib().od_flash_attn_bwd_fused(ops.dt_code(dtype), p(q), ld(q), p(k), ld(k), p(v), ld(v), p(o), ld(o), p(do), ld(do), p(lse),
+                                       p(dq), ld(dq), p(dk), ld(dk), p(dv), ld(dv), B, H, L - 70, hd, scale, 0, p(ws.buf), ws.bytes, ops._stream(q))
+    assert ws.status() == 2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ks", [3, 5])
 @pytest.mark.parametrize("L", [75, 21])          # long-run and short-run launch shapes (od_dwconv picks by size)
