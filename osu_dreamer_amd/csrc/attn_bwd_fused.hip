@@ -38,7 +38,8 @@ constexpr int FB_DS = FB_KB * 128;                // dS of one tile: [192 keys][
 #endif
 constexpr int FB_SLOTS = FB_NSLOTS;                          // (batch, head)s per XCD whose running tiles exist at a time (two are in flight; the buffer is reused)
 constexpr int FB_RUN_TILE = 4 * 4 * 64 * 4;          // floats of one (batch-head, query tile) of the running buffer: 4 waves x 4 pieces x 64 lanes x 4
-constexpr int FB_SMEM = 2 * FB_STAGE + 2 * FB_DS + 16;
+constexpr int FB_KST = 2 * FB_STAGE + 2 * FB_DS;     // the key block's K rows, staged once per job for the query waves (same image as a dS tile)
+constexpr int FB_SMEM = FB_KST + FB_DS + 16;
 
 #ifndef FB_ORDER
 #define FB_ORDER 3     // how a query wave orders its vector-memory work inside an iteration (1, 2: measured alternatives, profiles/r04ac)
@@ -47,7 +48,7 @@ constexpr int FB_SMEM = 2 * FB_STAGE + 2 * FB_DS + 16;
 #define FB_REQ 2       // the slab of the dQ product after which the running tile is requested
 #endif
 #ifndef FB_SPLIT
-#define FB_SPLIT 0     // how the four query waves split the dQ product of a tile (see there; 1, 2: measured alternatives, profiles/r04ae)
+#define FB_SPLIT 1     // how the four query waves split the dQ product of a tile (see there; 0, 2: measured alternatives, profiles/r04ae, r04al)
 #endif
 #ifndef FB_X
 #define FB_X 0        // timing experiments only (wrong dq): bit 0 = no chain traffic, bit 1 = no dQ products, bit 2 = no dS publication, bit 8 = no exp2, bit 9 = no transposed Q / dO reads after the first, bit 10 = no row-major Q / dO reads after the first, bit 3 = no running-tile loads,
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                                                                  FbSync* __restrict__ sync, int B, int H, int L, float scale) {
     constexpr int NK = FB_NK, KB = FB_KB;
     OD_DYN_SMEM(smem);
-    int* const s_job = (int*)(smem + 2 * FB_STAGE + 2 * FB_DS);
+    int* const s_job = (int*)(smem + FB_KST + FB_DS);
     const int BH = B * H, nkb = (L + KB - 1) / KB, nqt = (L + 63) / 64;
     const int jobs_per_xcd = ((BH + 7) / 8) * nkb;
     const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), x = lane & 15, g = lane >> 4;
@@ -349,31 +350,19 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
         } else {
             // =================================================================== query waves
             const int hh = wave - 4;
-            // The dQ product of a tile, dQ^T[64 features x 64 queries] = K^T[64 x 192 keys] dS[192 x 64], is split by FEATURES: wave h owns feature tile h
-            // (K^T slice in 24 registers, gathered once per job) for all four 16-query groups, and reads the whole dS image (48 transpose reads per
-            // tile).  A split by QUERIES reads a quarter of the image (12 reads; the whole K^T of the block in 96 registers) and is SLOWER, 24.8 ms per
-            // call against 22.6 (two features x two groups: 23.1): its four MFMAs per slab come back to back and hold up the key wave on the same
-            // SIMD, which is the pace of the workgroup; the LDS reads in between were spacing them out for free.  A operand of feature tile j, slab s
-            // (32 keys): row = feature 16 j + x, k-slot (g, i) = key 32 s + 8 g + i of the block.
+            // The dQ product of a tile, dQ^T[64 features x 64 queries] = K^T[64 x 192 keys] dS[192 x 64], is split by QUERIES: wave h owns query group h
+            // (16 queries) for all four feature tiles — it reads a quarter of the dS image (12 transpose reads per tile; a split by features reads
+            // all of it, 48) and holds the whole K^T of the block in 96 registers.  A operand of feature tile j, slab s (32 keys): row = feature
+            // 16 j + x, k-slot (g, i) = key 32 s + 8 g + i of the block: the transposed image of the block's K rows, which the four query waves stage
+            // in LDS once per job (DMA, in the dS image's swizzle) and read back with the same transpose reads as a dS tile.  (Gathered from global
+            // memory element by element — 192 two-byte loads per lane — the job's prologue cost more than the split saved: 23.2 ms per call against
+            // 21.6 for the split by features; staged, 20.8: profiles/r04al.)
             // (FB_SPLIT: 0 = by features — wave h owns feature tile h for all four query groups —, 1 = by queries, 2 = two feature tiles x two groups)
             constexpr int NJ = FB_SPLIT == 0 ? 1 : FB_SPLIT == 1 ? 4 : 2, NG = 4 / NJ;     // feature tiles / query groups of a wave; accumulator a = (ji, gi)
             auto ji_of = [](int a) FB_INLINE { return FB_SPLIT == 0 ? 0 : FB_SPLIT == 1 ? a : a >> 1; };
             auto gi_of = [](int a) FB_INLINE { return FB_SPLIT == 0 ? a : FB_SPLIT == 1 ? 0 : a & 1; };
             const int j0 = FB_SPLIT == 0 ? hh : FB_SPLIT == 1 ? 0 : 2 * (hh & 1), G0 = FB_SPLIT == 0 ? 0 : FB_SPLIT == 1 ? hh : 2 * (hh >> 1);
-            od_frag<bf16_t> fkt[NJ][6];
-#pragma unroll
-            for (int s = 0; s < 6; s++) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {                                // clamped address + select: independent loads, no branches
-                    const int key = kblk * KB + 32 * s + 8 * g + i;
-                    const bf16_t* kr = kb_ + (size_t)(key < L ? key : L - 1) * ldk + 16 * j0 + x;
-#pragma unroll
-                    for (int j = 0; j < NJ; j++) {
-                        const short kv = (short)kr[16 * j];
-                        fkt[j][s].v[i] = key < L ? kv : (short)0;
-                    }
-                }
-            }
+            od_frag<bf16_t> fkt[NJ][6];                                  // filled from the staged K rows after the job's first barrier (below)
             // Q / dO tile streaming: piece = 8 rows x 128 B; this wave moves pieces hh and hh + 4 of both tiles; waves 0 / 1 also move the
             // 64 start values (-lse', -delta).  Rows past L lie beyond the descriptors and read as zero.
             const od_srd_t rq = od_make_srd(qb, (unsigned)(((size_t)(L - 1) * ldq + 64) * 2));
@@ -382,6 +371,26 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             const int prow = lane >> 3, pslot = (lane & 7) ^ prow;          // tile_off<128>: slot ^ (row & 7), row & 7 = lane >> 3
             const unsigned vq = (unsigned)((hh * 8 + prow) * ldq * 2 + pslot * 16), vo = (unsigned)((hh * 8 + prow) * lddo * 2 + pslot * 16);
             const unsigned smem_a = od_lds_addr(smem);
+            // K rows of the block -> LDS: 24 pieces of 8 rows x 128 B, six per wave; LDS slot c of row r holds chunk c ^ fb_swz(r) (the swizzle is
+            // applied on the SOURCE address: the DMA writes linearly).  Rows past L lie beyond the descriptor and read as zero.
+            const od_srd_t rk = od_make_srd(kb_, (unsigned)(((size_t)(L - 1) * ldk + 64) * 2));
+            auto stage_k = [&]() FB_INLINE {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const int pc = hh + 4 * i;                          // piece: rows 8 pc .. 8 pc + 7 of the block
+                    const int r = 8 * pc + (lane >> 3);
+                    const unsigned vk = (unsigned)((lane >> 3) * ldk * 2 + (((lane & 7) ^ fb_swz(r)) << 4));
+                    od_buffer_lds16_at(rk, vk, (unsigned)od_uniform((kblk * KB + 8 * pc) * ldk * 2), (unsigned)od_uniform((int)(smem_a + (unsigned)FB_KST + (unsigned)pc * 1024u)));
+                }
+            };
+            int trk[NJ][2];                                              // transpose-read offsets of feature tile j0 + ji in the staged image (as tr_off below)
+#pragma unroll
+            for (int ji = 0; ji < NJ; ji++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int row = 8 * g + (x >> 2) + 4 * e;
+                    trk[ji][e] = row * 128 + (((2 * (j0 + ji) + ((x & 3) >> 1)) ^ fb_swz(row)) << 4) + (x & 1) * 8;
+                }
             // the tile DMA in five single-instruction pieces (0, 1: Q rows 0..31 / 32..63; 2, 3: dO; 4: the tile's -lse / -delta rows): a wave's vector-memory
             // instruction issues only when the CU's address pipeline (64 bytes per clock for the DMA, the running-tile loads AND stores: ~1000 clocks
             // per tile) takes it, so the pieces go out one at a time between the slabs of the dQ product instead of back to back in front of it
@@ -597,9 +606,19 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                 if (FB_PROF) { const unsigned long long t5 = FB_CLK(); ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; }
             };
             OD_DRAIN_VMEM();
+            stage_k();
             dma(0);
             FB_WAIT_ALL();
-            od_barrier_raw();                              // tile 0 visible to the key waves
+            od_barrier_raw();                              // tile 0 visible to the key waves, the staged K rows to the query waves
+#pragma unroll
+            for (int s = 0; s < 6; s++)
+#pragma unroll
+                for (int ji = 0; ji < NJ; ji++) {
+                    const s16x4 b0 = od_lds_tr_read((const bf16_t*)(smem + FB_KST + s * 4096 + trk[ji][0]));
+                    const s16x4 b1 = od_lds_tr_read((const bf16_t*)(smem + FB_KST + s * 4096 + trk[ji][1]));
+                    fkt[ji][s].v[0] = b0[0]; fkt[ji][s].v[1] = b0[1]; fkt[ji][s].v[2] = b0[2]; fkt[ji][s].v[3] = b0[3];
+                    fkt[ji][s].v[4] = b1[0]; fkt[ji][s].v[5] = b1[1]; fkt[ji][s].v[6] = b1[2]; fkt[ji][s].v[7] = b1[3];
+                }
             // it = 0: nothing to turn into dQ yet
             if (1 < nqt) dma(1);
             FB_WAIT_ALL();
@@ -708,7 +727,7 @@ extern "C" int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const 
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
     const FbLayout lay = fb_layout(B, H, L);
     if (ws_bytes < (long)lay.total) return OD_ERR_ARG;
-    if (((size_t)L * (size_t)(ldq > lddo ? ldq : lddo)) * 2 >= 0xffffffffull) return OD_ERR_UNSUPPORTED;      // 32-bit buffer offsets
+    if (((size_t)L * (size_t)(ldq > lddo ? (ldq > ldk ? ldq : ldk) : (lddo > ldk ? lddo : ldk))) * 2 >= 0xffffffffull) return OD_ERR_UNSUPPORTED;      // 32-bit buffer offsets
     hipStream_t st = (hipStream_t)stream;
     unsigned char* w = (unsigned char*)ws;
     float* nl = (float*)(w + lay.nl);
