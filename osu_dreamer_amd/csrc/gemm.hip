@@ -513,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict
 template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ C, int ldc,
-                                                            int M, int N, int K, int nt_store) {
+                                                            int M, int N, int K, int nt_store, RopeEpi rp) {
     using T = bf16_t;
     constexpr int TM = 256, TN = 256, STG = 65536;       // stage: A 32 KiB (256 rows x 128 B) then W 32 KiB
     OD_DYN_SMEM(smem);
@@ -685,6 +685,67 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
         // straight from the accumulators, which restart at that bias
         f32x4 bv[8];
         load_bias(more ? n1 : n0, bv);
+        if constexpr (EPI == OD_EPI_QKROPE) {
+            // q/k RMSNorm + RoPE (attn.py:74-80) on the accumulators, as in gemm_nt_big_kernel's epilogue: the wave's 128 columns are TWO heads
+            // (hd = 64); of head hq a lane holds columns 8g..8g+7 (acc[4hq], acc[4hq+1]) and 32+8g..+7 (acc[4hq+2], acc[4hq+3]) for row
+            // 16 j + x: the rotary partner (d, d + 32) is in the same lane, the head's sum of squares takes two shuffles.  The values are
+            // rounded to the tensor type first (what the unfused path reads back); with a second output (training) C keeps them.
+            T* qk = (T*)rp.qk_out;
+#pragma unroll
+            for (int hq = 0; hq < 2; hq++) {
+                const int hc0 = n0 + wn * 128 + 64 * hq;
+                const bool roped = hc0 < rp.n_rope, isq = hc0 < rp.dh;
+                float wv[2][8];
+                {
+                    const float* w = isq ? rp.wq : rp.wk;
+                    od_ld8(w + 8 * g, wv[0]); od_ld8(w + 32 + 8 * g, wv[1]);
+                }
+                const float qs = isq ? rp.q_scale : 1.f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int gm = m0 + wm * 128 + j * 16 + x;
+                    const bool valid = gm < M && hc0 < N;
+                    float v[2][8];
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            v[p][r] = od_round_to<T>(acc[4 * hq + 2 * p][j][r]);
+                            v[p][4 + r] = od_round_to<T>(acc[4 * hq + 2 * p + 1][j][r]);
+                        }
+                        acc[4 * hq + 2 * p][j] = bv[4 * hq + 2 * p]; acc[4 * hq + 2 * p + 1][j] = bv[4 * hq + 2 * p + 1];
+                    }
+                    T* crow = C + (size_t)(valid ? gm : 0) * ldc + hc0 + 8 * g;
+                    if (!roped || qk) {
+                        if (valid) {
+                            if (nt_store) { od_st8_nt(crow, v[0]); od_st8_nt(crow + 32, v[1]); }
+                            else { od_st8(crow, v[0]); od_st8(crow + 32, v[1]); }
+                        }
+                        if (!roped) continue;
+                    }
+                    float ss = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) ss += v[0][e] * v[0][e] + v[1][e] * v[1][e];
+                    ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+                    const float invs = rsqrtf(ss / 64.f + rp.eps) * qs;
+                    float t0[8], t1[8];                       // (cos, sin) of features 8g .. 8g+7 at this frame's position
+                    const float* tb = rp.table + ((size_t)((valid ? gm : 0) % rp.L) * 32 + 8 * g) * 2;
+                    od_ld8(tb, t0); od_ld8(tb + 8, t1);
+                    float o0[8], o1[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float y0 = v[0][e] * invs * wv[0][e], y1 = v[1][e] * invs * wv[1][e];
+                        const float cs = e < 4 ? t0[2 * e] : t1[2 * e - 8], sn = e < 4 ? t0[2 * e + 1] : t1[2 * e - 7];
+                        o0[e] = y0 * cs - y1 * sn;
+                        o1[e] = y1 * cs + y0 * sn;
+                    }
+                    if (valid) {
+                        T* dst = qk ? qk + (size_t)gm * rp.ldqk + hc0 + 8 * g : crow;
+                        od_st8(dst, o0); od_st8(dst + 32, o1);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int gm = m0 + wm * 128 + j * 16 + x;
@@ -1075,13 +1136,16 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
         if constexpr (std::is_same<T, bf16_t>::value) {
             static const int w4 = od_env_int("OD_NT_W4", 1);
             static const int w4_min_k = od_env_int("OD_NT_W4_MIN_K", 0);
-            if (w4 && epi != OD_EPI_QKROPE && !accumulate && K >= w4_min_k && K % 128 == 0) {
+            static const int w4_rope = od_env_int("OD_NT_W4_QKROPE", 1);      // (0: the 8-wave kernel's norm + RoPE epilogue; A/B)
+            if (w4 && (epi != OD_EPI_QKROPE || w4_rope) && !accumulate && K >= w4_min_k && K % 128 == 0) {
                 int pgrid = od_num_cus() & ~7;                 // persistent: one workgroup per CU, a multiple of 8 (block b runs on XCD b % 8)
                 pgrid = pgrid < 8 ? 8 : pgrid;
-                if (epi == OD_EPI_SILU)
-                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_SILU>), dim3(grid2 < pgrid ? grid2 : pgrid), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
+                if (epi == OD_EPI_QKROPE)
+                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_QKROPE>), dim3(grid2 < pgrid ? grid2 : pgrid), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, (rp.qk_out ? nt_store : 0), rp);
+                else if (epi == OD_EPI_SILU)
+                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_SILU>), dim3(grid2 < pgrid ? grid2 : pgrid), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store, rp);
                 else
-                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_NONE>), dim3(grid2 < pgrid ? grid2 : pgrid), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
+                    OD_LAUNCH_DYN((gemm_nt_w4_kernel<OD_EPI_NONE>), dim3(grid2 < pgrid ? grid2 : pgrid), dim3(256), 131072, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store, rp);
                 OD_CHECK_LAUNCH();
                 return 0;
             }
