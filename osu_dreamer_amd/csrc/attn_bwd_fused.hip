@@ -4,17 +4,19 @@
 // (which recomputes S and dP for dQ).  The obstacle to a 5-pass backward is dQ: a workgroup that owns a block of keys forms, for every
 // query tile, only ITS keys' share of dQ, and the chip's atomics (340 G fp32 / s) cannot sum those shares.  Here they are summed by a
 // CHAIN: the key blocks of one (batch, head) run on the compute units of one XCD at the same time, each adds its share to a running fp32
-// tile that travels block -> block through that XCD's L2 (plain stores, L1-bypassing loads, one flag per tile), and the last key block
-// writes the finished bf16 dQ.  No atomics on data, a fixed summation order (deterministic), no extra pass over memory.
+// tile that travels block -> block through that XCD's L2 (plain stores, L1-bypassing loads; no flags: every 16-byte piece carries the number
+// of the write it belongs to), and the last key block writes the finished bf16 dQ.  No atomics on data, a fixed summation order
+// (deterministic), no extra pass over memory.
 //
-// Workgroup = 8 waves on one CU, two ROLES (one wave of each per SIMD):
+// Workgroup = 8 waves on one CU, two ROLES (one wave of each per SIMD), each with its own job loop:
 //   * waves 0-3 ("key waves") own 48 keys each (192 per workgroup) with K, V fragments and the dK, dV accumulators in registers, exactly as
 //     flash_bwd_dkv_kernel does: per 64-query tile  S = Q K^T ; P = 2^S ; dP = dO V^T ; dS = P (dP - delta) ; dV^T += dO^T P ; dK^T += Q^T dS.
-//     They touch no global memory inside the loop, and publish dS (bf16) to LDS as [key][query].
-//   * waves 4-7 ("query waves") stream the Q / dO tiles (LDS-DMA), and turn the published dS of the PREVIOUS tile into dQ: wave h owns
-//     features 16h..16h+15 of the tile, dQ^T[16 x 64 queries] = K^T[16 x 192 keys] dS^T[192 x 64], K^T slice in registers, dS^T by LDS
-//     transpose reads — the contraction over the workgroup's 192 keys happens inside the MFMA chain, so no cross-wave reduction exists.
-//     Then they run the chain step for that tile (software-pipelined over three loop iterations so no memory latency is exposed).
+//     They touch no global memory inside the loop, and publish dS (bf16) to LDS as [key][query].  They are the pace of the workgroup.
+//   * waves 4-7 ("query waves") stream the Q / dO tiles (LDS-DMA, issued piece by piece between their MFMAs), and turn the published dS of
+//     the PREVIOUS tile into dQ: wave h owns 16 of the tile's 64 queries, dQ^T[64 features x 16] = K^T[64 x 192 keys] dS[192 x 16], the block's
+//     K^T in registers (read once per job from an LDS image of its K rows), its quarter of dS by LDS transpose reads — the contraction over
+//     the workgroup's 192 keys happens inside the MFMA chain, so no cross-wave reduction exists.  Then they run the chain step for a tile
+//     whose running sum has arrived (an elastic ring of four shares: a late predecessor costs an iteration of lag, not a stall).
 // The grid is persistent (one workgroup per CU); workgroups take (batch-head, key-block) jobs from a queue PER XCD (by the hardware's XCC id),
 // in order, so a job's predecessor in the chain was always taken earlier: it is running or done, never waiting for a free CU.
 #include "od_common.h"
