@@ -109,6 +109,21 @@ constexpr int OD_EPI_QKROPE = 2;
 
 // WMT = 16-row MFMA tiles per wave along m: 4 -> 128 x 128 block tile, 2 -> 64 x 128 (twice the workgroups, for
 // launches whose 128-row tiling would leave CUs idle: the sampler's M = B*L = 4460 against N = 512)
+// LDS stages of gemm_nt_kernel and its dynamic LDS size.  At the sampler's sizes (M = 4460: one workgroup per CU, 16-44 k-tiles of ~0.15 us of
+// MFMAs each) an iteration of the two-stage loop lasts one fetch latency (~1 us); with three stages two fetches are in flight.
+#ifndef OD_GEMM_NT_STAGES3
+#define OD_GEMM_NT_STAGES3 2       // 1: three stages for every type at WMT <= 2; 2: not for plain fp32; 0: never
+#endif
+template <class T, bool DMA, int WMT>
+constexpr int gemm_nt_stages() {
+    return (DMA && (WMT <= 2 || OD_GEMM_NT_STAGES3 == 3) && (OD_GEMM_NT_STAGES3 == 1 || (OD_GEMM_NT_STAGES3 >= 2 && !std::is_same<T, float>::value))) ? 3 : 2;
+}
+template <class T, bool DMA, int WMT>
+constexpr int gemm_nt_smem_bytes() {
+    constexpr int stg = 32 * WMT * 128 + 16384, csz = 32 * WMT * 512, n = gemm_nt_stages<T, DMA, WMT>();
+    return n * stg > csz ? n * stg : csz;
+}
+
 template <class T, int EPI, bool DMA, int WMT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                       const float* __restrict__ bias, T* __restrict__ C, int ldc,
@@ -116,9 +131,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
     constexpr int BK = 128 / (int)sizeof(T);  // elements per slab row
     constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
     constexpr int ASZ = 32 * WMT * 128;                    // A tile bytes per stage (BMT rows x 128 B)
-    constexpr int STG = ASZ + 16384;                       // + W tile: 48 KiB of LDS at WMT = 2, 64 at 4
+    constexpr int STG = ASZ + 16384;                       // + W tile
     constexpr int CSZ = 32 * WMT * 512;                    // epilogue image, f32 [BMT][128]
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG > CSZ ? 2 * STG : CSZ];
+    constexpr int NSTG = gemm_nt_stages<T, DMA, WMT>();       // DMA, WMT <= 2: three stages (two tiles in flight), 60 / 72 KiB — two workgroups per CU still fit
+    OD_DYN_SMEM(smem);                                     // gemm_nt_smem_bytes<T, DMA, WMT>()
+    static_assert(NSTG * STG >= CSZ || !DMA || WMT == 4, "");
 
     constexpr int BMT = 32 * WMT;
     const int tiles_m = (M + BMT - 1) / BMT, tiles_n = (N + BN - 1) / BN;
@@ -175,21 +192,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, i
                 const int slot = (lane & 7) ^ (row & 7);
                 const int k = kt * BK + slot * CH;
                 int br = n0 + row; br = br < N ? br : N - 1;
-                od_glds16(W + (size_t)br * ldw + k, sB + (wave * 4 + i) * 1024 + lane * 16);
+                if constexpr (NSTG == 3) od_glds16_async(W + (size_t)br * ldw + k, sB + (wave * 4 + i) * 1024);
+                else od_glds16(W + (size_t)br * ldw + k, sB + (wave * 4 + i) * 1024 + lane * 16);
                 if (i < WMT) {
                     const int rowa = (wave * WMT + i) * 8 + (lane >> 3);     // same (row & 7), hence the same slot
                     int ar = m0 + rowa; ar = ar < M ? ar : M - 1;
-                    od_glds16(A + (size_t)ar * lda + k, sA + (wave * WMT + i) * 1024 + lane * 16);
+                    if constexpr (NSTG == 3) od_glds16_async(A + (size_t)ar * lda + k, sA + (wave * WMT + i) * 1024);
+                    else od_glds16(A + (size_t)ar * lda + k, sA + (wave * WMT + i) * 1024 + lane * 16);
                 }
             }
         };
-        dma(0, 0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt++) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
-            compute_stage<T, WMT>(smem + buf * STG, smem + buf * STG + ASZ, wm, wn, lane, acc);
+        // asm DMA with hand-counted waits (the builtin form is waited for in front of the next LDS read): a wave has 4 + WMT pieces per tile
+        if constexpr (NSTG == 3) {
+            dma(0, 0);
+            if (1 < nk) dma(1, 1);
+            if (1 < nk) { if (WMT == 1) OD_WAIT_VMCNT(5); else if (WMT == 2) OD_WAIT_VMCNT(6); else OD_WAIT_VMCNT(8); } else OD_WAIT_VMCNT(0);       // tile 0 has landed
+            od_barrier_raw();
+            int buf = 0;
+            for (int kt = 0; kt < nk; kt++) {
+                const int nb = buf == 2 ? 0 : buf + 1, fb = nb == 2 ? 0 : nb + 1;      // stages of tiles kt + 1, kt + 2 (the latter was tile kt - 1's: free since the last barrier)
+                if (kt + 2 < nk) dma(kt + 2, fb);
+                compute_stage<T, WMT>(smem + buf * STG, smem + buf * STG + ASZ, wm, wn, lane, acc);
+                if (kt + 2 < nk) { if (WMT == 1) OD_WAIT_VMCNT(5); else if (WMT == 2) OD_WAIT_VMCNT(6); else OD_WAIT_VMCNT(8); } else OD_WAIT_VMCNT(0);   // tile kt + 1 has landed
+                od_barrier_raw();
+                buf = nb;
+            }
+        } else {
+            dma(0, 0);                                     // (the builtin DMA: an asm one with the wait behind the compute measured +1 % at two stages)
             __syncthreads();
+            for (int kt = 0; kt < nk; kt++) {
+                const int buf = kt & 1;
+                if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+                compute_stage<T, WMT>(smem + buf * STG, smem + buf * STG + ASZ, wm, wn, lane, acc);
+                __syncthreads();
+            }
         }
     } else {
     gload(0);
@@ -1161,7 +1197,7 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
         return 0;
     }
     if (epi == OD_EPI_QKROPE && rp.qk_out) return OD_ERR_UNSUPPORTED;      // the split form exists in the large-M kernel only (callers check)
-#define NT_GO(EPI_, DMA_, WMT_) OD_LAUNCH((gemm_nt_kernel<T, EPI_, DMA_, WMT_>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, rp)
+#define NT_GO(EPI_, DMA_, WMT_) OD_LAUNCH_DYN((gemm_nt_kernel<T, EPI_, DMA_, WMT_>), dim3(grid), dim3(256), (gemm_nt_smem_bytes<T, DMA_, WMT_>()), st, A, lda, W, ldw, bias, C, ldc, M, N, K, accumulate, rp)
 #define NT_GO2(EPI_, DMA_) do { if (quarter) NT_GO(EPI_, DMA_, 1); else if (half) NT_GO(EPI_, DMA_, 2); else NT_GO(EPI_, DMA_, 4); } while (0)
     if (epi == OD_EPI_QKROPE) {
         if (dma) NT_GO2(OD_EPI_QKROPE, true); else NT_GO2(OD_EPI_QKROPE, false);

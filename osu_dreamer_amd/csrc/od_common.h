@@ -279,6 +279,17 @@ __device__ __forceinline__ void od_glds16(const void* g, void* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 #endif
+// The same from inline asm (see the note at od_buffer_lds16_at: the builtin form is waited for, with vmcnt(0), in front of the NEXT LDS read of
+// any address — nothing can be fetched more than one tile ahead).  `lds_base`: the wave's destination base (lane i lands at lds_base + 16 i),
+// wave-uniform.  The caller counts: OD_WAIT_VMCNT before the barrier that publishes a tile.
+#if defined(OD_EMU)
+__device__ __forceinline__ void od_glds16_async(const void* g, void* lds_base) { emu::global_load_lds16(g, (unsigned char*)lds_base + 16 * emu::lane_id()); }
+#else
+__device__ __forceinline__ void od_glds16_async(const void* g, void* lds_base) {
+    const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
+}
+#endif
 
 // Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... lds): descriptor (base, byte size) + per-lane byte offset (VGPR) +
 // wave-uniform byte offset (SGPR).  The per-tile address arithmetic is then ONE scalar add instead of 64-bit vector math per
