@@ -317,10 +317,12 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(L_cpu=2048):
-    """The CPU oracle (a port of the reference path, pinned by tests/golden) timed on this box's
-    host cores on a bounded sample: ONE fp32 training step at batch 1 x L_cpu frames, scaled to the
-    metric's unit by frames (a bench step is 32 x 8192 frames)."""
+def cpu_baseline(L_cpu=2048, B=32, L=8192):
+    """The CPU oracle (a port of the reference path, pinned by tests/golden) timed on this box's host cores on a bounded sample: ONE fp32
+    training step at batch 1 x L_cpu frames.  `value` scales the sample to the bench step (B x L frames) by ALGORITHMIC FLOPs — the closed
+    form of SURVEY.md section 8d, 3 x frames x (68,244,644 + 32,768 L): attention's cost per frame grows with L, so scaling by frames alone
+    (reported beside it) over-states the CPU rate.  `--cpu-frames 8192` times batch 1 at the bench's own L instead (minutes, tens of GB of
+    host memory for the oracle's dense attention), and then only the batch factor is extrapolated."""
     from oracle import denoiser_oracle as O
     cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
@@ -335,11 +337,35 @@ def cpu_baseline(L_cpu=2048):
     _, coef = O.clip_coef(grads, 1.0)
     O.adamw_ema_step(P, grads, m, vv, ema, 1, 3e-4, clip=coef, first_ema=True)
     dt = time.time() - t0
-    frames_per_s = L_cpu / dt
-    return {"value": frames_per_s / (32 * 8192), "unit": "train-steps/s (32x8192-frame step equivalent, EXTRAPOLATED by frames from the timed sample)",
+    by_flops = dt * flops_forward(B * L, L) / flops_forward(L_cpu, L_cpu)      # seconds per bench step, scaled by algorithmic FLOPs
+    by_frames = dt * (B * L) / L_cpu
+    return {"value": 1.0 / by_flops,
+            "unit": f"train-steps/s ({B}x{L}-frame step equivalent, EXTRAPOLATED from the timed sample by algorithmic FLOPs: frames x (68,244,644 + 32,768 L))",
             "cores": cores, "cpu": cpu_model(), "kind": "port",
-            "sample": f"1 fp32 train step, batch 1 x {L_cpu} frames, {dt:.1f} s, {frames_per_s:.0f} frames/s; "
-                      f"attention cost grows with L, so this over-states the CPU rate at L=8192"}
+            "sample": f"1 fp32 train step, batch 1 x {L_cpu} frames, {dt:.1f} s, {L_cpu / dt:.0f} frames/s at that length",
+            "value_scaled_by_frames_only": 1.0 / by_frames,
+            "extrapolation": {"sample_frames": L_cpu, "sample_seconds": round(dt, 2), "flops_factor": round(flops_forward(B * L, L) / flops_forward(L_cpu, L_cpu), 2),
+                              "frames_factor": round(B * L / L_cpu, 2), "same_length_as_bench": L_cpu == L}}
+
+
+def allreduce_alone(reducer, device, iters=3):
+    """The gradient exchange with nothing beside it: the arena's segments all-reduced back to back on the launch stream (every rank calls
+    this), HIP events around them.  The figure the N-rank line's exposed time and SURVEY section 8(e)'s 0.3 - 2.1 ms are read against.
+    (At world size 1 an in-place ncclAllReduce launches nothing: the time is the enqueue cost.)"""
+    g = reducer.model.arena.ensure_grad()
+    segs = [g[s:e] for s, e in reducer.segments.values()]
+    def run():
+        for t in segs:
+            reducer.comm.allreduce_mean_(t)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, sum(t.numel() * 4 for t in segs), len(segs)
 
 
 def sampler_bench(device):
@@ -478,6 +504,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8192)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / sampler legs")
+    ap.add_argument("--cpu-frames", type=int, default=2048, help="length of the CPU baseline's batch-1 sample (8192 = the bench's own L: minutes)")
     args = ap.parse_args()
 
     # --gpus N: one process per GPU.  Outside a torchrun job this process only starts the N ranks (as children,
@@ -554,6 +581,7 @@ def main():
         per_rank = torch.stack(allr).cpu()
         dt = float(per_rank[:, 0].max()) * args.steps / 1e3
     final_loss = float(loss.detach())
+    alone = allreduce_alone(reducer, device) if ddp else None        # every rank: a collective
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -590,6 +618,11 @@ def main():
         if ddp:
             line["collective"] = {"backend": "RCCL via od_allreduce_grads", "version": reducer.comm.version,
                                   "exchange": "od_allreduce_grads per arena segment (187.5 MB fp32 per step), overlapped with backward",
+                                  "bytes_per_step": alone[1], "buckets_per_step": alone[2],
+                                  # the same ten all-reduces with nothing beside them (HIP events, after the timed region): what the ring costs
+                                  # when it does not have to share the chip (SURVEY section 8e expects 0.3 - 2.1 ms at 8 ranks over xGMI)
+                                  "allreduce_alone_ms": round(alone[0], 3),
+                                  "allreduce_alone_gb_per_s": round(alone[1] / max(alone[0], 1e-6) / 1e6, 1),
                                   "world_size": world, "rccl_ranks_seen": reducer.comm.ranks_seen,
                                   # time the compute stream waited for the side-stream exchange before clip / AdamW (HIP events): mean
                                   # over steps, averaged and maximised over ranks; 0 = fully hidden under the backward
@@ -601,15 +634,20 @@ def main():
                                   "ms_per_step_per_rank": [round(float(x), 2) for x in per_rank[:, 0]],
                                   "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                                   "comm_stream_priority": int(os.environ.get("OD_COMM_STREAM_PRIORITY", "0"))}
-        if not args.no_extras and world == 1:
+        if not args.no_extras:
+            # rank 0 only; at N > 1 the other ranks wait in the barrier below (their GPUs idle): the dominant kernel is re-timed on
+            # rank 0's GPU and the CPU baseline on the host cores, so that an N-rank line carries the same two objects as the N = 1 line
             line["calibration"] = mfma_calibration(device)
             line["ms_per_step_x_sustained_tflops"] = round(ms * line["calibration"]["sustained_tflops"], 1)     # comparable between boxes and rounds
             line["roofline"] = roofline_of_dominant_kernel(tr, B, L)
-            line["pcie_inclusive"] = h2d_leg(batch, device, ms)
-            line["forward_64x8192"] = forward_target_shape(tr, device)
-            line["sampler"] = sampler_bench(device)
-            line["ldm_sample"] = ldm_bench(device)
-            line["cpu_baseline"] = cpu_baseline()
+            if world == 1:
+                line["pcie_inclusive"] = h2d_leg(batch, device, ms)
+                line["forward_64x8192"] = forward_target_shape(tr, device)
+                line["sampler"] = sampler_bench(device)
+                line["ldm_sample"] = ldm_bench(device)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_frames, B, L)
+            if world > 1:
+                line["cpu_baseline"]["note"] = "timed on rank 0's host while the other ranks waited in a barrier"
     else:
         line = None
     if ddp:

@@ -159,14 +159,19 @@ int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const void* k, int 
  * atomics on data), and the last key block writes dq.  `ws` is caller-owned device memory of od_flash_attn_bwd_fused_ws_bytes(...) bytes whose first
  * *zero_out bytes are zero before the first call; one workspace serves any number of calls of ONE (B, H, L) on one stream (zero it again
  * before a launch of another shape: the running tiles carry write numbers that continue from launch to launch).
- * od_flash_attn_bwd_fused_status copies the workspace's sticky error word to the host (it synchronises the device: a test / debug aid):
- * 0 = every launch processed all of its jobs, 1 = a launch left jobs unprocessed, 2 = a launch with another (B, H, L) than the workspace's
- * earlier launches was refused (nothing was computed).  replaces: autograd of attn.py:82. */
+ * od_flash_attn_bwd_fused_status copies the workspace's sticky error word to the host (the copy is enqueued on `stream` — the stream of the
+ * launches — and waited for): 0 = every launch processed all of its jobs, 1 = a launch left jobs unprocessed, 2 = a launch with another
+ * (B, H, L) than the workspace's earlier launches was refused (nothing was computed), 3 = a chain wait ran out of time (the predecessor's
+ * write never came — a workspace that was not zero, or was left mid-launch by an aborted process): that launch TERMINATED and wrote NaN into dq;
+ * zero the workspace's head again before reusing it.  The wait's budget is OD_FB_CHAIN_TIMEOUT_MS (environment, default 1000).
+ * The same word can be folded into the step on the device: od_sqnorm / od_adamw_ema take its address (workspace + ..._err_offset()).
+ * replaces: autograd of attn.py:82. */
 int od_flash_attn_bwd_fused_ws_bytes(int B, int H, int L, long* total_out, long* zero_out);
 int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
                             const void* dout, int lddo, const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
                             int B, int H, int L, int hd, float scale, int q_prescaled, void* ws, long ws_bytes, void* stream);
-int od_flash_attn_bwd_fused_status(const void* ws, int* err_out);
+int od_flash_attn_bwd_fused_status(const void* ws, int* err_out, void* stream);
+int od_flash_attn_bwd_fused_err_offset(void);
 int od_flash_attn_bwd_fused_passes(void);
 /* profiling builds (-DFB_PROF=1) only: 16 cycle counters of the workspace, copied out and cleared; zeros otherwise. */
 int od_flash_attn_bwd_fused_prof(void* ws, long* out16);
@@ -228,13 +233,16 @@ int od_sampler_step(float* x, const float* u, const float* v, const float* eta, 
 int od_sampler_eta(const float* u, float* eta, int B, float c0, int num_steps, void* stream);
 
 /* ---- optimizer (models/diffusion/train.py:110-126; model.yml:39) --------------------- */
-/* out[0] += sum g^2. */
-int od_sqnorm(const float* g, long n, float* out, void* stream);
+/* out[0] += sum g^2.  `status` (may be NULL): device address of an error word of an earlier kernel of the step — the fused attention
+ * backward's, workspace + od_flash_attn_bwd_fused_err_offset().  Non-zero there turns out[0] into NaN on the device: every step is checked
+ * without a host synchronisation (replaces nothing in the reference; the clip it feeds is model.yml:39). */
+int od_sqnorm(const float* g, long n, float* out, const int* status, void* stream);
 /* clip by global norm (gnorm_sq device scalar, max_norm<=0 disables) -> AdamW -> EMA, one pass.
- * ema_mode: 0 none, 1 copy (first update), 2 lerp with (1-ema_decay). */
+ * ema_mode: 0 none, 1 copy (first update), 2 lerp with (1-ema_decay).
+ * `status` (may be NULL): as for od_sqnorm; non-zero there SKIPS the update (parameters, moments and the average are left untouched). */
 int od_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float ema_decay, int ema_mode, const float* gnorm_sq,
-                 float max_norm, void* stream);
+                 float max_norm, const int* status, void* stream);
 
 /* EMA only: mode 1 copy, mode 2 ema += (1-decay)*(p-ema).  replaces: train.py:125-126 when the
  * average is updated outside the fused pass. */
@@ -304,6 +312,10 @@ int od_comm_destroy(void* comm);
 int od_comm_abort(void* comm);
 /* number of ranks RCCL itself counts in the communicator (ncclCommCount), or a negative error: the bench line's `rccl_ranks_seen` */
 int od_comm_count(void* comm);
+/* Test aid for boxes with one GPU (a single-rank ncclAllReduce in place launches nothing): the footprint of a ring all-reduce on the
+ * kernels beside it — `channels` workgroups of `threads` (256 / 512 / 1024) threads, resident for the whole call, each streaming its slice of
+ * buf[count] (read, written back unchanged) `rounds` times.  Not part of the reference's path. */
+int od_comm_ring_standin(float* buf, long count, int channels, int threads, int rounds, void* stream);
 /* grads[0:count] (fp32, device) <- sum over ranks (average != 0: mean) in place, enqueued on `stream`: the one exchange
  * of a data-parallel training step (the gradient of train.py:120-123's loss over the global batch). */
 int od_allreduce_grads(void* comm, float* grads, long count, int average, void* stream);

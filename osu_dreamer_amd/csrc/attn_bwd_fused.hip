@@ -24,6 +24,7 @@
 #include "od_api_internal.h"
 #include <type_traits>
 #include <stddef.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -77,7 +78,8 @@ struct FbSync {
     int head[8];          // next job of each XCD's queue
     int finished;         // workgroups that have left the job loop
     int jobs_done;        // jobs processed (all XCDs)
-    int err;              // sticky: 1 = a launch ended with unprocessed jobs (an XCD without workgroups)
+    int err;              // sticky: 1 = a launch ended with unprocessed jobs (an XCD without workgroups), 2 = shape mismatch (refused),
+                          // 3 = a chain wait ran out of time (the predecessor's write never came): dq of that launch is NaN
     int calls;            // completed launches on this workspace: its number is in every running-tile tag
     int shape[3];         // B, H, L of the launches this workspace has served (0 = none yet): slot numbering and layout depend on them
     int pad;
@@ -90,6 +92,18 @@ struct FbSync {
 __device__ __forceinline__ unsigned fb_f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float fb_u2f(unsigned x) { return __builtin_bit_cast(float, x); }
 
+// a quiet NaN the compiler cannot see through (this file is built with -ffinite-math-only: a NaN it knew of would be undefined behaviour)
+__device__ __forceinline__ float fb_poison() {
+#if defined(OD_EMU)
+    volatile unsigned bits = 0x7fc00000u;
+    return fb_u2f(bits);
+#else
+    float x;
+    asm volatile("v_mov_b32 %0, 0x7fc00000" : "=v"(x));
+    return x;
+#endif
+}
+
 __device__ __forceinline__ int fb_swz(int row) { return (row & 7) ^ (((row >> 3) & 1) << 2); }
 
 #if defined(OD_EMU)
@@ -100,6 +114,8 @@ struct fb_rsrc_t { const unsigned char* base; };
 __device__ __forceinline__ fb_rsrc_t fb_make_rsrc(const float* base, unsigned) { return fb_rsrc_t{(const unsigned char*)base}; }
 __device__ __forceinline__ f32x4 fb_ld_l2(fb_rsrc_t r, unsigned voff, unsigned soff) { return *(const f32x4*)(r.base + voff + soff); }
 __device__ __forceinline__ void fb_sleep() {}
+// the emulator runs the workgroups one after the other: a predecessor's write is either there or will never come — every poll costs one "tick"
+__device__ __forceinline__ unsigned long long fb_now(unsigned polls) { return polls; }
 __device__ __forceinline__ int fb_atomic_inc(int* p) { return atomicAdd(p, 1); }
 #define FB_WAIT_ALL() ((void)0)
 #define FB_COMPILER_FENCE() ((void)0)
@@ -126,6 +142,8 @@ __device__ __forceinline__ f32x4 fb_ld_l2(fb_rsrc_t r, unsigned voff, unsigned s
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, FB_LD_AUX));
 }
 __device__ __forceinline__ void fb_sleep() { __builtin_amdgcn_s_sleep(4); }
+// the constant 100 MHz counter (s_memrealtime): the budget of a chain wait is wall time, whatever the shader clock does
+__device__ __forceinline__ unsigned long long fb_now(unsigned) { return __builtin_amdgcn_s_memrealtime(); }
 __device__ __forceinline__ int fb_atomic_inc(int* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // everything this wave has issued to memory is complete (loads landed, stores acknowledged by the L2)
 #define FB_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -168,7 +186,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                                                                  const float* __restrict__ nl, const float* __restrict__ nd,
                                                                  bf16_t* __restrict__ dq, int lddq, bf16_t* __restrict__ dk, int lddk,
                                                                  bf16_t* __restrict__ dv, int lddv, float* __restrict__ run,
-                                                                 FbSync* __restrict__ sync, int B, int H, int L, float scale) {
+                                                                 FbSync* __restrict__ sync, int B, int H, int L, float scale,
+                                                                 unsigned wait_ticks) {
     constexpr int NK = FB_NK, KB = FB_KB;
     OD_DYN_SMEM(smem);
     int* const s_job = (int*)(smem + FB_KST + FB_DS);
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             // with its predecessor thus falls one iteration behind it WITHOUT holding up its own workgroup, and from then on every request
             // finds its tile: neither the L2 round trip nor the predecessor's jitter is ever inside the workgroup's barrier interval.
             int done = 0;
-            bool inflight = false;
+            bool inflight = false, aborted = false;
             auto chain_request = [&](int produced) FB_INLINE {                     // top of an iteration: tiles < produced have their share in the ring
                 if ((FB_X & 1) || inflight || done >= produced) return;
                 chain_load(done, rb);
@@ -563,11 +582,31 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                 }
                 while (done < must_reach) {                              // the ring is full (or the job ends): now it has to be waited for
                     four = false;
-                    for (;;) {
-                        FB_COMPILER_FENCE();                             // every reload is a NEW read of memory another CU is writing
-                        chain_load(done, rb);
-                        if (tags_good(rb)) break;
-                        fb_sleep();
+                    // BOUNDED: a predecessor that never publishes (a workspace that was not zeroed, or was left mid-launch by an aborted process; a
+                    // launch whose tags do not continue the workspace's) must not hang the GPU — and, under data parallelism, every rank behind
+                    // it.  After `wait_ticks` of the 100 MHz counter (~1 s by default) the wave gives up: sticky err = 3, the tile it could not
+                    // get is replaced by NaNs (they travel down the chain into dq, and the tags it writes let its successors pass), and every
+                    // other wait of the launch ends as soon as it sees the word.  The launch then terminates in its normal time.
+                    if (!aborted) {
+                        unsigned long long t_start = 0;
+                        for (unsigned polls = 0;; polls++) {
+                            FB_COMPILER_FENCE();                         // every reload is a NEW read of memory another CU is writing
+                            chain_load(done, rb);
+                            if (tags_good(rb)) break;
+                            if ((polls & 15u) == 15u) {
+                                const unsigned long long now = fb_now(polls);
+                                if (polls == 15u) t_start = now;
+                                else if (now - t_start > (unsigned long long)wait_ticks) aborted = true;
+                                if (od_uniform(fb_flag_load(&sync->err)) == 3) aborted = true;
+                                if (aborted) break;
+                            }
+                            fb_sleep();
+                        }
+                    }
+                    if (aborted) {
+                        if (lane == 0) fb_flag_store(&sync->err, 3);
+#pragma unroll
+                        for (int G = 0; G < 4; G++) rb[G] = (f32x4)(fb_poison());
                     }
                     commit_dyn(done);
                     done++;
@@ -687,25 +726,44 @@ inline FbLayout fb_layout(int B, int H, int L) {
     const size_t BH = (size_t)B * H, nqt = (size_t)(L + 63) / 64;
     FbLayout l;
     l.sync = 0;
-    l.nl = fb_align(sizeof(FbSync));
+    l.run = fb_align(sizeof(FbSync));
+    l.nl = l.run + fb_align((size_t)8 * FB_SLOTS * nqt * FB_RUN_TILE * sizeof(float));      // [0, nl): what has to be zero before the first launch
     l.nd = l.nl + fb_align(BH * L * sizeof(float));
-    l.run = l.nd + fb_align(BH * L * sizeof(float));
-    (void)BH;
-    l.total = l.run + fb_align((size_t)8 * FB_SLOTS * nqt * FB_RUN_TILE * sizeof(float));
+    l.total = l.nd + fb_align(BH * L * sizeof(float));
     return l;
+}
+
+// Budget of one blocking chain wait in ticks of the 100 MHz counter: OD_FB_CHAIN_TIMEOUT_MS (default 1000; read once).  A healthy launch never
+// waits longer than a few microseconds (the predecessor is running or done by construction); the bound exists so that a corrupt workspace ends
+// as status 3 + NaN gradients instead of a hung GPU.
+inline unsigned fb_wait_ticks() {
+    static const unsigned ticks = [] {
+        const char* e = getenv("OD_FB_CHAIN_TIMEOUT_MS");
+        long ms = e ? atol(e) : 1000;
+        if (ms < 1) ms = 1;
+        if (ms > 40000) ms = 40000;
+#if defined(OD_EMU)
+        return (unsigned)1024;                 // emulator: polls, not time
+#else
+        return (unsigned)(ms * 100000);
+#endif
+    }();
+    return ticks;
 }
 
 }  // namespace
 
-// Bytes of the caller-owned workspace of od_flash_attn_bwd_fused (*total_out) and of its head (*zero_out: control block + chain flags), which must
-// be ZERO before the first launch; every launch leaves it zero again.
+// Bytes of the caller-owned workspace of od_flash_attn_bwd_fused (*total_out) and of its head (*zero_out: the control block and the running
+// tiles), which must be ZERO before the first launch (the start values behind it are written by every launch before they are read).
 extern "C" int od_flash_attn_bwd_fused_ws_bytes(int B, int H, int L, long* total_out, long* zero_out) {
     if (B <= 0 || H <= 0 || L <= 0 || !total_out || !zero_out) return OD_ERR_ARG;
     const FbLayout lay = fb_layout(B, H, L);
     *total_out = (long)lay.total;
-    *zero_out = (long)lay.total;
+    *zero_out = (long)lay.nl;
     return 0;
 }
+// byte offset of the sticky error word (an int) inside a workspace: od_sqnorm takes its address and folds it into the gradient norm ON THE DEVICE
+extern "C" int od_flash_attn_bwd_fused_err_offset(void) { return (int)offsetof(FbSync, err); }
 extern "C" int od_flash_attn_bwd_fused_passes(void) { return 5; }
 // FB_PROF builds: copies the 16 cycle counters to the host and clears them
 extern "C" int od_flash_attn_bwd_fused_prof(void* ws, long* out16) {
@@ -714,6 +772,7 @@ extern "C" int od_flash_attn_bwd_fused_prof(void* ws, long* out16) {
 #if defined(OD_EMU)
     s = *(FbSync*)ws;
 #else
+    if (hipDeviceSynchronize() != hipSuccess) return OD_ERR_ARG;      // (a profiling aid: the blocking copy alone orders against the null stream only)
     if (hipMemcpy(&s, ws, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) return OD_ERR_ARG;
     if (hipMemset((unsigned char*)ws + offsetof(FbSync, prof), 0, sizeof(s.prof)) != hipSuccess) return OD_ERR_ARG;
 #endif
@@ -739,7 +798,7 @@ extern "C" int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const 
               q_prescaled ? FB_LOG2E : 1.0f / scale);
     const int grid = od_num_cus();
 #define FB_ARGS dim3(grid), dim3(512), FB_SMEM, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)dout, lddo, \
-        (const float*)nl, (const float*)nd, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, (float*)(w + lay.run), (FbSync*)(w + lay.sync), B, H, L, scale
+        (const float*)nl, (const float*)nd, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, (float*)(w + lay.run), (FbSync*)(w + lay.sync), B, H, L, scale, fb_wait_ticks()
 #define FB_LAUNCH_X(...) OD_LAUNCH_DYN(__VA_ARGS__)      /* lets the argument-list macro expand first */
     if (q_prescaled) FB_LAUNCH_X((flash_bwd_fused_kernel<true>), FB_ARGS);
     else FB_LAUNCH_X((flash_bwd_fused_kernel<false>), FB_ARGS);
@@ -749,16 +808,20 @@ extern "C" int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const 
     return 0;
 }
 
-// the sticky error word of a workspace (0 = every launch processed every job); a host-side read, synchronises the stream's device
-extern "C" int od_flash_attn_bwd_fused_status(const void* ws, int* err_out) {
+// the sticky error word of a workspace (0 = every launch processed every job); a host-side read: the copy is enqueued on `stream` — the
+// stream the launches went to — and that stream is waited for (a blocking hipMemcpy would order against the null stream only, and the
+// streams torch hands out do not synchronise with it)
+extern "C" int od_flash_attn_bwd_fused_status(const void* ws, int* err_out, void* stream) {
     if (!ws || !err_out) return OD_ERR_ARG;
 #if defined(OD_EMU)
+    (void)stream;
     *err_out = ((const FbSync*)ws)->err;
 #else
-    FbSync s;
-    hipError_t e = hipMemcpy(&s, ws, sizeof(s), hipMemcpyDeviceToHost);
+    int v = -1;
+    hipError_t e = hipMemcpyAsync(&v, (const unsigned char*)ws + offsetof(FbSync, err), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return -(int)e - 1000;
-    *err_out = s.err;
+    *err_out = v;
 #endif
     return 0;
 }

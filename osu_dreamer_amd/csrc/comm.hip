@@ -20,6 +20,7 @@ extern "C" int od_comm_abort(void*) { return OD_ERR_UNSUPPORTED; }
 extern "C" int od_comm_count(void*) { return OD_ERR_UNSUPPORTED; }
 extern "C" int od_allreduce_grads(void*, float*, long, int, void*) { return OD_ERR_UNSUPPORTED; }
 extern "C" int od_broadcast_f32(void*, float*, long, int, void*) { return OD_ERR_UNSUPPORTED; }
+extern "C" int od_comm_ring_standin(float*, long, int, int, int, void*) { return OD_ERR_UNSUPPORTED; }
 #else
 #include <dlfcn.h>
 #include <string.h>
@@ -125,6 +126,29 @@ extern "C" int od_broadcast_f32(void* comm, float* buf, long count, int root, vo
     if (!comm || !g_rccl.handle || count < 0) return OD_ERR_ARG;
     if (count == 0) return 0;
     if (g_rccl.Broadcast(buf, buf, (size_t)count, kNcclFloat32, root, (ncclComm_t)comm, (hipStream_t)stream) != 0) return OD_ERR_COMM;
+    return 0;
+}
+
+// What a ring all-reduce looks like to the kernels it runs beside, for boxes with ONE GPU (a single-rank ncclAllReduce in place launches
+// nothing): `channels` long-lived workgroups of `threads` threads, each streaming its slice of `buf` (read + write back unchanged,
+// 16 bytes per lane) `rounds` times — resident on `channels` CUs for the whole exchange and drawing HBM bandwidth, like RCCL's channel
+// kernels.  The soak of the fused attention backward (tools/soak_fused.py, tests/test_ddp_rccl.py) runs it on the exchange's side stream.
+namespace {
+__global__ void ring_standin_kernel(float* buf, long n4, int rounds) {
+    const long per = (n4 + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+    f32x4* b4 = (f32x4*)buf;
+    for (int r = 0; r < rounds; r++)
+        for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            f32x4 v = __builtin_nontemporal_load(b4 + i);
+            asm volatile("" : "+v"(v));
+            __builtin_nontemporal_store(v, b4 + i);
+        }
+}
+}  // namespace
+extern "C" int od_comm_ring_standin(float* buf, long count, int channels, int threads, int rounds, void* stream) {
+    if (!buf || count < 4 || channels < 1 || channels > 1024 || rounds < 1 || (threads != 256 && threads != 512 && threads != 1024)) return OD_ERR_ARG;
+    hipLaunchKernelGGL(ring_standin_kernel, dim3(channels), dim3(threads), 0, (hipStream_t)stream, buf, count / 4, rounds);
+    OD_CHECK_LAUNCH();
     return 0;
 }
 #endif

@@ -727,19 +727,38 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
             // 16 j + x: the rotary partner (d, d + 32) is in the same lane, the head's sum of squares takes two shuffles.  The values are
             // rounded to the tensor type first (what the unfused path reads back); with a second output (training) C keeps them.
             T* qk = (T*)rp.qk_out;
+#ifndef OD_W4Q_X
+#define OD_W4Q_X 0        // experiments (profiles/r05b): 1 no table loads (wrong), 2 qk stored non-temporally, 4 no qk stores (wrong), 8 C stored plainly
+#endif
+            const bool c_nt = nt_store && !(OD_W4Q_X & 8);
+            // rows outer, the wave's two heads inner: the (cos, sin) row of a frame is loaded once for both
+            float wv[2][2][8];
+            bool roped2[2], isq2[2];
 #pragma unroll
             for (int hq = 0; hq < 2; hq++) {
                 const int hc0 = n0 + wn * 128 + 64 * hq;
-                const bool roped = hc0 < rp.n_rope, isq = hc0 < rp.dh;
-                float wv[2][8];
-                {
-                    const float* w = isq ? rp.wq : rp.wk;
-                    od_ld8(w + 8 * g, wv[0]); od_ld8(w + 32 + 8 * g, wv[1]);
-                }
-                const float qs = isq ? rp.q_scale : 1.f;
+                roped2[hq] = hc0 < rp.n_rope; isq2[hq] = hc0 < rp.dh;
+                const float* w = isq2[hq] ? rp.wq : rp.wk;
+                od_ld8(w + 8 * g, wv[hq][0]); od_ld8(w + 32 + 8 * g, wv[hq][1]);
+            }
+            const bool any_roped = roped2[0] || roped2[1];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int gm = m0 + wm * 128 + j * 16 + x;
+            for (int j = 0; j < 8; j++) {
+                const int gm = m0 + wm * 128 + j * 16 + x;
+                float t0[8], t1[8];                           // (cos, sin) of features 8g .. 8g+7 at this frame's position
+                if (any_roped) {
+                    if (OD_W4Q_X & 1) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) { t0[e] = (e & 1) ? 0.f : 1.f; t1[e] = t0[e]; }
+                    } else {
+                        const float* tb = rp.table + ((size_t)((gm < M ? gm : 0) % rp.L) * 32 + 8 * g) * 2;
+                        od_ld8(tb, t0); od_ld8(tb + 8, t1);
+                    }
+                }
+#pragma unroll
+                for (int hq = 0; hq < 2; hq++) {
+                    const int hc0 = n0 + wn * 128 + 64 * hq;
+                    const bool roped = roped2[hq];
                     const bool valid = gm < M && hc0 < N;
                     float v[2][8];
 #pragma unroll
@@ -754,7 +773,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                     T* crow = C + (size_t)(valid ? gm : 0) * ldc + hc0 + 8 * g;
                     if (!roped || qk) {
                         if (valid) {
-                            if (nt_store) { od_st8_nt(crow, v[0]); od_st8_nt(crow + 32, v[1]); }
+                            if (c_nt) { od_st8_nt(crow, v[0]); od_st8_nt(crow + 32, v[1]); }
                             else { od_st8(crow, v[0]); od_st8(crow + 32, v[1]); }
                         }
                         if (!roped) continue;
@@ -763,21 +782,19 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
 #pragma unroll
                     for (int e = 0; e < 8; e++) ss += v[0][e] * v[0][e] + v[1][e] * v[1][e];
                     ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-                    const float invs = rsqrtf(ss / 64.f + rp.eps) * qs;
-                    float t0[8], t1[8];                       // (cos, sin) of features 8g .. 8g+7 at this frame's position
-                    const float* tb = rp.table + ((size_t)((valid ? gm : 0) % rp.L) * 32 + 8 * g) * 2;
-                    od_ld8(tb, t0); od_ld8(tb + 8, t1);
+                    const float invs = rsqrtf(ss / 64.f + rp.eps) * (isq2[hq] ? rp.q_scale : 1.f);
                     float o0[8], o1[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        const float y0 = v[0][e] * invs * wv[0][e], y1 = v[1][e] * invs * wv[1][e];
+                        const float y0 = v[0][e] * invs * wv[hq][0][e], y1 = v[1][e] * invs * wv[hq][1][e];
                         const float cs = e < 4 ? t0[2 * e] : t1[2 * e - 8], sn = e < 4 ? t0[2 * e + 1] : t1[2 * e - 7];
                         o0[e] = y0 * cs - y1 * sn;
                         o1[e] = y1 * cs + y0 * sn;
                     }
-                    if (valid) {
+                    if (valid && !(OD_W4Q_X & 4)) {
                         T* dst = qk ? qk + (size_t)gm * rp.ldqk + hc0 + 8 * g : crow;
-                        od_st8(dst, o0); od_st8(dst + 32, o1);
+                        if ((OD_W4Q_X & 2) && qk) { od_st8_nt(dst, o0); od_st8_nt(dst + 32, o1); }
+                        else { od_st8(dst, o0); od_st8(dst + 32, o1); }
                     }
                 }
             }

@@ -8,8 +8,12 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+// `status` (optional): a device-side error word of an earlier kernel of the step (the fused attention backward's, attn_bwd_fused.hip).  Non-zero
+// poisons the norm: NaN + anything = NaN whatever the order of the blocks' atomics — no host round trip, checked in EVERY step.
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ out,
+                                                     const int* __restrict__ status) {
     __shared__ float sh[4];
+    if (status && blockIdx.x == 0 && threadIdx.x == 0 && status[0] != 0) atomicAdd(out, __builtin_nanf(""));
     float s = 0.f;
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -28,7 +32,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
                                                         float* __restrict__ v, float* __restrict__ ema, long n, float lr,
                                                         float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
                                                         float ema_decay, int ema_mode, const float* __restrict__ gnorm_sq,
-                                                        float max_norm) {
+                                                        float max_norm, const int* __restrict__ status) {
+    if (status && status[0] != 0) return;        // gradients of a failed launch: the step is skipped (the host raises at its next check)
     float clip = 1.f;
     if (max_norm > 0.f && gnorm_sq) {
         const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);
@@ -66,23 +71,23 @@ extern "C" int od_ema_update(float* ema, const float* p, long n, float ema_decay
     return 0;
 }
 
-extern "C" int od_sqnorm(const float* g, long n, float* out, void* stream) {
+extern "C" int od_sqnorm(const float* g, long n, float* out, const int* status, void* stream) {
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    OD_LAUNCH(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    OD_LAUNCH(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out, status);
     OD_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int od_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int step, float ema_decay, int ema_mode, const float* gnorm_sq,
-                            float max_norm, void* stream) {
+                            float max_norm, const int* status, void* stream) {
     if (step < 1 || n <= 0) return OD_ERR_ARG;
     if (ema_mode != 0 && !ema) return OD_ERR_ARG;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
     OD_LAUNCH(adamw_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, lr, beta1, beta2, eps,
-              weight_decay, bc1, bc2_sqrt, ema_decay, ema_mode, gnorm_sq, max_norm);
+              weight_decay, bc1, bc2_sqrt, ema_decay, ema_mode, gnorm_sq, max_norm, status);
     OD_CHECK_LAUNCH();
     return 0;
 }

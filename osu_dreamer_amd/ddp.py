@@ -141,10 +141,14 @@ class GradBucketReducer:
         self.bucket_log.append((name, e - s))   # the order the collectives were enqueued in (tests: identical on every rank)
         if g.is_cuda and self.overlap:
             if self._comm_stream is None:
-                # OD_COMM_STREAM_PRIORITY: 0 (default) = a plain side stream; -1 = high, 1 = LOW priority — the exchange's kernels then
-                # take CUs only when the backward leaves them free (for the first real multi-GPU run to A/B against CU contention)
+                # OD_COMM_STREAM_PRIORITY: 0 (default) = a plain side stream; -1 = HIGH priority — the exchange's workgroups are dispatched
+                # ahead of the backward's (the knob for the first real multi-GPU A/B: the ring's latency against the CUs it takes).  The
+                # runtime clamps positive values to 0 (0 already is the lowest priority a stream can have): they are refused here rather
+                # than recorded in a bench line as if they had meant something.
                 import os
                 prio = int(os.environ.get("OD_COMM_STREAM_PRIORITY", "0"))
+                if prio > 0:
+                    raise ValueError("OD_COMM_STREAM_PRIORITY > 0 has no effect (HIP clamps it to the default); use 0 or -1")
                 self._comm_stream = torch.cuda.Stream(g.device, priority=prio) if prio else torch.cuda.Stream(g.device)
             self._comm_stream.wait_stream(torch.cuda.current_stream(g.device))
             with torch.cuda.stream(self._comm_stream):

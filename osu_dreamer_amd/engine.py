@@ -79,8 +79,11 @@ class DenoiserEngine:
         # (the sampler's hipGraph) is stale from then on
         self.generation = 0
         self._attn_aux = None
-        self._attn_ws = None          # workspace of the fused (5-pass) attention backward, per (B, H, L)
-        self._attn_ws_checked = False
+        # workspaces of the fused (5-pass) attention backward, one per (B, H, L, device) that has run (a ragged last batch or a second
+        # sequence length alternates between two of them without re-allocating, re-zeroing or synchronising); `_attn_ws` = the one the
+        # last backward used: its sticky error word is folded into every optimizer step on the device (attn_status_ptr)
+        self._attn_ws_cache: Dict[tuple, "ops.FusedAttnBwdWorkspace"] = {}
+        self._attn_ws = None
 
     # ------------------------------------------------------------------ parameters
     def P(self, name: str) -> torch.Tensor:
@@ -302,9 +305,14 @@ class DenoiserEngine:
         scale = 1.0 / math.sqrt(self.hd)
         dqk = self.buf("d.qk", (self.M, 2 * dh))
         if self.fused_attn_bwd():
-            if self._attn_ws is None or self._attn_ws.shape != (self.B, self.H, self.L) or self._attn_ws.buf.device != qk.device:
-                self._attn_ws = ops.FusedAttnBwdWorkspace(self.B, self.H, self.L, qk.device)
-                self._attn_ws_checked = False
+            key = (self.B, self.H, self.L, qk.device)
+            ws = self._attn_ws_cache.get(key)
+            if ws is None:
+                if len(self._attn_ws_cache) >= 4:              # bounded: the oldest shape goes
+                    self._attn_ws_cache.pop(next(iter(self._attn_ws_cache)))
+                ws = self._attn_ws_cache[key] = ops.FusedAttnBwdWorkspace(self.B, self.H, self.L, qk.device)
+                ws.checked = False
+            self._attn_ws = ws
             ops.flash_attn_bwd_fused(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:],
                                      self.B, self.H, self.L, self.hd, scale, self._attn_ws, q_prescaled=True)
         else:
@@ -431,9 +439,28 @@ class DenoiserEngine:
         if reducer is not None:
             reducer.segment_done("head")
         # The fused attention backward draws its jobs from one queue per XCD and needs every XCD to run at least one of its workgroups (observed
-        # on every launch so far: block b runs on XCD b % 8).  Its workspace keeps a sticky error word for the case that one did not; read it
-        # once, after the first backward of a plan (one device synchronisation), and refuse to train on silently incomplete gradients.
-        if self._attn_ws is not None and not self._attn_ws_checked:
-            self._attn_ws_checked = True
-            if self._attn_ws.status() != 0:
-                raise RuntimeError("od_flash_attn_bwd_fused left jobs unprocessed (an XCD without workgroups); set OD_ATTN_BWD_FUSED=0")
+        # on every launch so far: block b runs on XCD b % 8), and its chain waits are bounded.  Its workspace keeps a sticky error word for the
+        # launches where either went wrong.  EVERY step checks it on the device: FusedAdamWEMA hands attn_status_ptr() to od_sqnorm /
+        # od_adamw_ema (norm -> NaN, update skipped) and the trainer raises at its next logging point (check_attn_status).  The first backward
+        # on a workspace is also checked here, on the host (one stream synchronisation per shape): fail before the first optimizer step.
+        if self.fused_attn_bwd() and self._attn_ws is not None and not self._attn_ws.checked:
+            self._attn_ws.checked = True
+            self.check_attn_status()
+
+    def attn_status_ptr(self) -> int:
+        """Device address of the sticky error word of the fused attention backward the last `backward` used (0: none ran)."""
+        return self._attn_ws.err_ptr() if self._attn_ws is not None else 0
+
+    ATTN_STATUS = {1: "a launch left jobs unprocessed (an XCD ran none of its workgroups): gradients incomplete",
+                   2: "a launch with another (B, H, L) than the workspace's earlier launches was refused",
+                   3: "a chain wait ran out of time (the predecessor's write never came; OD_FB_CHAIN_TIMEOUT_MS): dq is NaN"}
+
+    def check_attn_status(self):
+        """Host-side read of that word (waits for the current stream).  Raises on anything but 0; the optimizer steps since the failing
+        launch were skipped on the device."""
+        if self._attn_ws is None:
+            return
+        code = self._attn_ws.status()
+        if code != 0:
+            raise RuntimeError(f"od_flash_attn_bwd_fused status {code}: {self.ATTN_STATUS.get(code, '?')}; the optimizer steps since then "
+                               "were skipped.  OD_ATTN_BWD_FUSED=0 selects the two-kernel backward.")

@@ -204,6 +204,8 @@ class Trainer:
                 sched.step()
                 module.on_train_batch_end()
                 self.global_step += 1
+                if self.global_step % self.log_every_n_steps == 0:
+                    opt.check_device_status()          # EVERY rank: a failed launch on one rank must end the job, not train on
                 if self.global_step % self.log_every_n_steps == 0 and self.rank == 0:
                     rec = {"step": self.global_step, "epoch": self.epoch, "lr": opt.param_groups[0]["lr"],
                            "s_per_step": (time.time() - t_last) / self.log_every_n_steps,
@@ -225,6 +227,7 @@ class Trainer:
         return self.history
 
     def _validate_and_checkpoint(self, module, datamodule, device, opt, sched):
+        opt.check_device_status()                      # never checkpoint past a failed launch
         val = self.validate(module, datamodule, device)
         if self.rank != 0:
             return

@@ -278,14 +278,23 @@ class FusedAttnBwdWorkspace:
         self.shape = (B, H, L)
         self.bytes = total.value
         assert zero.value <= self.bytes
+        self.zero_bytes = zero.value
         self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
-        self.buf[:zero.value].zero_()          # once: control block and running tiles (a zero tile never carries a valid tag)
+        self.reset()
+
+    def reset(self):
+        """Zero the control block and the running tiles (a zero tile carries write number 0): once at creation, and again after a status-3 launch."""
+        self.buf[:self.zero_bytes].zero_()
+
+    def err_ptr(self) -> int:
+        """Device address of the sticky error word: ops.sqnorm / ops.adamw_ema fold it into the step without a host round trip."""
+        return self.buf.data_ptr() + int(_lib.lib().cdll.od_flash_attn_bwd_fused_err_offset())
 
     def status(self) -> int:
-        """The sticky error word (0 = every launch processed all of its jobs).  Synchronises the device."""
+        """The sticky error word (0 = every launch processed all of its jobs; 1 / 2 / 3: see the header).  Waits for the current stream."""
         import ctypes
         err = ctypes.c_int(-1)
-        _lib.lib().od_flash_attn_bwd_fused_status(_p(self.buf), ctypes.byref(err))
+        _lib.lib().od_flash_attn_bwd_fused_status(_p(self.buf), ctypes.byref(err), _stream(self.buf))
         return err.value
 
 
@@ -405,15 +414,16 @@ def sampler_eta(u, eta, c0, num_steps):
 
 
 # ---------------------------------------------------------------- optimizer
-def sqnorm(g, out):
+def sqnorm(g, out, status_ptr: int = 0):
+    """out[0] += sum g^2; `status_ptr` (a device address, 0 = none): non-zero error word -> out[0] = NaN, on the device."""
     _f32(g, out)
-    _lib.lib().od_sqnorm(_p(g), g.numel(), _p(out), _stream(g))
+    _lib.lib().od_sqnorm(_p(g), g.numel(), _p(out), status_ptr or None, _stream(g))
 
 
-def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, weight_decay, step, ema_decay, ema_mode, gnorm_sq, max_norm):
+def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, weight_decay, step, ema_decay, ema_mode, gnorm_sq, max_norm, status_ptr: int = 0):
     _f32(p, g, m, v, ema, gnorm_sq)
     _lib.lib().od_adamw_ema(_p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                            ema_decay, ema_mode, _p(gnorm_sq), max_norm, _stream(p))
+                            ema_decay, ema_mode, _p(gnorm_sq), max_norm, status_ptr or None, _stream(p))
 
 
 def ema_update(ema, p, decay, mode):

@@ -53,9 +53,14 @@ class FusedAdamWEMA(torch.optim.Optimizer):
         grp = self.param_groups[0]
         self.step_count += 1
         clip = float(self.max_grad_norm) if self.max_grad_norm else 0.0
-        if clip > 0:
+        # the fused attention backward's sticky error word, folded into the step ON THE DEVICE, every step: a failed launch (incomplete
+        # or NaN dq) turns the norm into NaN and the update below into a no-op; the trainer raises at its next logging point
+        # (DenoiserEngine.check_attn_status) — no host synchronisation here
+        eng = getattr(model, "_engine", None)
+        status = eng.attn_status_ptr() if eng is not None else 0
+        if clip > 0 or status:
             self.gnorm_sq.zero_()
-            ops.sqnorm(g, self.gnorm_sq)
+            ops.sqnorm(g, self.gnorm_sq, status)
         ema_buf, ema_mode, decay = None, 0, 0.0
         if self.ema is not None:
             ema_buf = self.ema.module.arena.data
@@ -63,8 +68,15 @@ class FusedAdamWEMA(torch.optim.Optimizer):
             decay = self.ema.decay
             self.ema.fused_pending += 1
         ops.adamw_ema(d, g, self.exp_avg, self.exp_avg_sq, ema_buf, grp["lr"], grp["betas"][0], grp["betas"][1],
-                      grp["eps"], grp["weight_decay"], self.step_count, decay, ema_mode, self.gnorm_sq, clip)
+                      grp["eps"], grp["weight_decay"], self.step_count, decay, ema_mode, self.gnorm_sq, clip, status)
         return loss
+
+    def check_device_status(self):
+        """Raise if a kernel of an earlier step reported an error on the device (one small stream-ordered read: call it where the host
+        synchronises anyway — logging, validation, checkpoints)."""
+        eng = getattr(self.model, "_engine", None)
+        if eng is not None:
+            eng.check_attn_status()
 
     # flat-state checkpointing (resume via --ckpt-path)
     def state_dict(self):

@@ -117,3 +117,18 @@ def test_bench_line_through_the_rccl_path():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["collective"]["backend"].startswith("RCCL") and d["collective"]["version"] > 0
     assert d["final_loss"] == d["final_loss"] and d["value"] > 0
+
+
+@pytest.mark.parametrize("priority", [0, -1])
+def test_fused_attention_backward_beside_the_exchange(priority):
+    """od_flash_attn_bwd_fused with the gradient exchange of a data-parallel step running beside it on the side stream — od_allreduce_grads on
+    the arena's ten segments plus od_comm_ring_standin (resident channel workgroups streaming each bucket: what RCCL's ring kernels occupy;
+    a one-rank all-reduce in place launches nothing) — at the bench shape: every launch's dq / dk / dv bit-identical to the quiet launch,
+    status 0, with the side stream at default and at high priority.  (tools/soak_fused.py runs the same for 200 steps:
+    profiles/r05_soak_fused_exchange.txt.)"""
+    from osu_dreamer_amd import _lib
+    _lib._lib = None
+    _lib.lib()
+    from tools.soak_fused import soak
+    rec = soak(4, 32, 8192, mode="exchange", priority=priority, channels=32, threads=512, rounds=40)
+    assert rec["differ"] == 0 and rec["status"] == 0 and rec["grads_intact"], rec

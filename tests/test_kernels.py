@@ -612,6 +612,50 @@ def test_flash_attn_bwd_fused_refuses_another_shape(dev):
     assert ws.status() == 2
 
 
+def test_flash_attn_bwd_fused_corrupt_workspace_terminates(dev):
+    """A workspace whose running tiles do not carry the write numbers a launch expects (not zeroed, or left mid-launch by an aborted process):
+    the chain wait is BOUNDED — the launch must terminate (no hung GPU), report status 3 and poison dq with NaN; the device-side fold turns
+    the gradient norm into NaN and the optimizer update into a no-op; after a reset the workspace serves again."""
+    hd, dtype, B, H, L = 64, torch.bfloat16, 1, 2, 400
+    g = torch.Generator().manual_seed(6)
+    M, dh = B * L, H * hd
+    q, k, v, do = (mk((M, dh), g, dev, dtype) for _ in range(4))
+    o = torch.zeros(M, dh, dtype=dtype, device=dev)
+    lse = torch.zeros(B, H, L, device=dev)
+    scale = 1 / math.sqrt(hd)
+    ops.flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale)
+    os.environ["OD_FB_CHAIN_TIMEOUT_MS"] = "50"          # read once per process, before the first fused launch (harmless if it already was)
+    ws = ops.FusedAttnBwdWorkspace(B, H, L, dev)
+    dq, dk, dv = (torch.zeros(M, dh, dtype=dtype, device=dev) for _ in range(3))
+    ops.flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, scale, ws)
+    assert ws.status() == 0
+    good = dq.float().cpu().clone()
+    # garbage write numbers in every running tile (the control block, 256 bytes, stays intact)
+    ws.buf[256:ws.zero_bytes].view(torch.int32).fill_(5)
+    ops.flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, scale, ws)
+    assert ws.status() == 3                                # ... and we got here: the launch ended
+    assert torch.isnan(dq.float()).any()
+    # the same word folded into the step on the device: norm -> NaN, update skipped
+    n = 1000
+    gr, p0 = mk((n,), g, dev), mk((n,), g, dev)
+    p, m, vv, ema = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    gn = torch.zeros(1, device=dev)
+    ops.sqnorm(gr, gn, ws.err_ptr())
+    assert torch.isnan(gn).all()
+    ops.adamw_ema(p, gr, m, vv, ema, 3e-4, .9, .999, 1e-8, .01, 1, .99, 1, gn, 1.0, ws.err_ptr())
+    assert torch.equal(p, p0) and float(m.abs().sum()) == 0 and float(ema.abs().sum()) == 0
+    # a healthy word changes nothing
+    ws.reset()
+    assert ws.status() == 0
+    gn.zero_()
+    ops.sqnorm(gr, gn, ws.err_ptr())
+    assert abs(float(gn) - float((gr.double() ** 2).sum())) < 1e-3 * float(gn)
+    ops.adamw_ema(p, gr, m, vv, ema, 3e-4, .9, .999, 1e-8, .01, 1, .99, 1, gn, 1.0, ws.err_ptr())
+    assert not torch.equal(p, p0)
+    ops.flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, scale, ws)
+    assert ws.status() == 0 and torch.equal(dq.float().cpu(), good)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ks", [3, 5])
 @pytest.mark.parametrize("L", [75, 21])          # long-run and short-run launch shapes (od_dwconv picks by size)

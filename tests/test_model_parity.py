@@ -306,6 +306,41 @@ def test_fused_attention_backward_in_the_step(dev, monkeypatch):
     assert rel_l2(grads["1"][1], grads["0"][1]) < 2e-3
 
 
+def test_failed_attention_backward_is_caught_in_every_step(dev, monkeypatch):
+    """The fused attention backward's sticky error word is folded into EVERY optimizer step on the device (no host round trip): after a good
+    first step, a launch on a workspace whose write numbers were damaged ends with status 3 and NaN dq — the gradient norm turns NaN, the
+    AdamW / EMA update is skipped (weights bit-identical to before) and the trainer's host-side check raises."""
+    monkeypatch.setenv("OD_ATTN_BWD_FUSED", "1")
+    monkeypatch.setenv("OD_FB_CHAIN_TIMEOUT_MS", "50")
+    d = O.Dims(global_cond_dim=64, backbone_dim=128, n_heads=2, head_dim=64, depth=2, expand=2, radius=1, u_head_dim=16)
+    P = O.init_params(d, seed=11)
+    data = O.synthetic_batch(d, 2, 230, seed=12)
+    tr = make_trainer(d, P, dev)
+    model = tr.diffusion
+    model.compute_dtype = torch.bfloat16
+    dd = {k: v.to(dev) for k, v in data.items()}
+    opt = tr.configure_optimizers()["optimizer"]
+    opt.max_grad_norm = 1.0
+
+    def step():
+        opt.zero_grad()
+        loss, _ = tr(model, dd["h"], dd["z"], dd["s"], None, t=dd["t"], x0=dd["x0"])
+        loss.backward()
+        opt.step()
+    step()
+    opt.check_device_status()                              # healthy: nothing raised
+    assert torch.isfinite(opt.gnorm_sq).all()
+    before = model.arena.data.detach().clone()
+    m_before = opt.exp_avg.clone()
+    ws = model.engine._attn_ws
+    ws.buf[256:ws.zero_bytes].view(torch.int32).fill_(5)   # damaged write numbers in every running tile
+    step()
+    assert torch.isnan(opt.gnorm_sq).all()
+    assert torch.equal(model.arena.data, before) and torch.equal(opt.exp_avg, m_before)
+    with pytest.raises(RuntimeError, match="status 3"):
+        opt.check_device_status()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # validation_step (train.py:128-139) against the reference's logs: segmenting of the full map, EMA weights, no_grad
 def run_validation_case(name, dev):
