@@ -268,7 +268,7 @@ def roofline_of_dominant_kernel(tr, B, L):
     t = eng.ws.t
     H, hd, dh = eng.H, eng.hd, eng.dh
     i = eng.depth - 1
-    qk, qkv, y, lse = t[f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
+    qk, qkv, y, lse = t[f"qk16.{i}" if eng.attn_f16 else f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
     dy, dqkv, delta = t["d.y"], t["d.qkv"], t["d.delta"]
     scale = 1 / math.sqrt(hd)
 
@@ -278,7 +278,7 @@ def roofline_of_dominant_kernel(tr, B, L):
         eng.attn_bwd_launch(i, dy, delta, dqkv, core_only=True)
 
     def fwd():
-        ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, H, L, hd, scale, q_prescaled=True)
+        ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], eng._v_of(qkv), y, lse, B, H, L, hd, scale, q_prescaled=True)
     unit = 2.0 * B * H * L * L * hd                 # one L x L x hd MFMA pass over all heads
     t_bwd, t_fwd = time_kernel(bwd), time_kernel(fwd)
     executed = bwd_passes_executed(eng)
@@ -503,6 +503,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=8192)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--attn-dtype", default="bf16", choices=["bf16", "f16"],
+                    help="f16: the attention core on IEEE-half operands (BASELINE configs[4] 'attention in fp16'; bf16 compute around it)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / sampler legs")
     ap.add_argument("--cpu-frames", type=int, default=2048, help="length of the CPU baseline's batch-1 sample (8192 = the bench's own L: minutes)")
     args = ap.parse_args()
@@ -533,6 +535,8 @@ def main():
     B, L = args.batch, args.frames
     tr = make_trainer(device, seed=1234)
     tr.diffusion.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.attn_dtype == "f16":
+        tr.diffusion.attn_dtype = torch.float16
     cfg = tr.configure_optimizers()
     opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
     if ddp:
@@ -590,8 +594,13 @@ def main():
         # executed MFMA work: forward + 2x GEMM backward + attention backward as its executed passes (vs 2 forward)
         attn_fwd = frames * 32_768 * L
         executed = f_fwd + 2 * (f_fwd - attn_fwd) + bwd_passes_executed(tr.diffusion.engine) / 2 * attn_fwd
-        named = {(32, 8192): "BASELINE.json configs[1]", (8, 32768): "BASELINE.json configs[4] shape; attention in bf16 MFMA where configs[4] says fp16 (same MFMA rate, no loss scaling)",
+        f16a = args.attn_dtype == "f16"
+        named = {(32, 8192): "BASELINE.json configs[1]",
+                 (8, 32768): ("BASELINE.json configs[4] shape, attention in fp16 with MFMA: q, k, v, P, dS and the staged dO are IEEE half (v_mfma_f32_*_f16), bf16 compute around the core"
+                              if f16a else "BASELINE.json configs[4] shape; attention in bf16 MFMA (--attn-dtype f16 runs it in fp16)"),
                  (2, 4096): "BASELINE.json configs[0] shape, on the GPU"}.get((B, L), "custom --batch/--frames")
+        if f16a and (B, L) != (8, 32768):
+            named += "; attention core on IEEE-half operands (--attn-dtype f16)"
         if world > 1 and (B, L) == (32, 8192):
             named = f"BASELINE.json configs[2] pattern at {world} ranks (configs[1] per rank)"
         line = {
@@ -599,7 +608,7 @@ def main():
             "value": round(world * args.steps / dt, 4), "unit": f"train-steps/s (rank-steps of batch {B} x {L} frames)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "attn_dtype": args.attn_dtype, "data": "synthetic",
             "config": {"workload": f"denoiser training step, batch={B} per GPU, {L}-frame synthetic latents, {args.dtype} "
                                    f"({named}); per-rank batch fixed under --gpus N",
                        "per_gpu_batch": B, "global_batch": B * world, "frames": L, "params": 46_877_103,

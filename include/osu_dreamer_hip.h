@@ -33,7 +33,12 @@ enum { OD_F32 = 0, OD_BF16 = 1,
         * 32 bf16 high halves followed by 32 bf16 low halves (same bytes and leading dimension as the fp32 matrix; K % 32 == 0).  The weights
         * of a sampler call are constant over its 51 evaluations: splitting them once takes half of the split work out of every GEMM.
         * Accepted by od_gemm_nt / od_gemm_nt_qkrope and od_pack_weight. */
-       OD_F32X3W = 3 };
+       OD_F32X3W = 3,
+       /* "attention in fp16" (BASELINE configs[4]; the reference's trainer option precision: 16-mixed, model.yml:12): the operands of the attention
+        * MFMAs are IEEE half — q, k, v in memory, P / dS and the staged dO inside the kernels (v_mfma_f32_*_f16, fp32 accumulation) — while
+        * everything around the attention core stays bf16: o, dO, dq, dk, dv are bf16 tensors.  Accepted by od_flash_attn_fwd,
+        * od_flash_attn_bwd_fused(+_ws_bytes), od_qk_norm_rope and, as `qk_dtype`, by od_gemm_nt_qkrope_split (head_dim 64 only). */
+       OD_F16 = 4 };
 enum { OD_EPI_NONE = 0, OD_EPI_SILU = 1 };
 enum { OD_ACT_NONE = 0, OD_ACT_SILU = 1 };
 enum { OD_ERR_ARG = -1, OD_ERR_ALIGN = -2, OD_ERR_UNSUPPORTED = -3, OD_ERR_COMM = -4 };
@@ -59,9 +64,11 @@ int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* W, int ldw,
                       float q_scale, void* stream);
 /* the training-time form of the above: C[M,N] keeps the pre-norm projection (the backward of the norm needs it) and the normed +
  * rotated q, k go to qk_out[M, 2*H*hd].  One launch at training sizes (bf16, hd 64, M >= 32768: the norm + RoPE run in the large-M
- * GEMM's epilogue); otherwise od_gemm_nt followed by od_qk_norm_rope.  replaces: attn.py:74-80. */
+ * GEMM's epilogue); otherwise od_gemm_nt followed by od_qk_norm_rope.  replaces: attn.py:74-80.
+ * qk_dtype: the element type of qk_out — dtype itself, or OD_F16 ("attention in fp16", bf16 GEMM, hd 64): qk_out AND the v columns of C
+ * (from 2*H*hd on) then hold IEEE half, rounded once from the fp32 accumulators; C's q / k columns stay bf16 (the norm's backward reads them). */
 int od_gemm_nt_qkrope_split(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
-                            void* qk_out, int ldqk, int M, int N, int K, const float* wq, const float* wk, const float* table,
+                            void* qk_out, int ldqk, int qk_dtype, int M, int N, int K, const float* wq, const float* wk, const float* table,
                             int L, int H, int hd, float eps, float q_scale, void* stream);
 /* dW[N,K] (fp32, ld lddw) += G[M,N]^T A[M,K]; if dbias != NULL also dbias[N] += column sums of G
  * — autograd weight and bias gradients of the above, G read once. */
@@ -166,7 +173,7 @@ int od_flash_attn_bwd_aux(int dtype, const void* q, int ldq, const void* k, int 
  * zero the workspace's head again before reusing it.  The wait's budget is OD_FB_CHAIN_TIMEOUT_MS (environment, default 1000).
  * The same word can be folded into the step on the device: od_sqnorm / od_adamw_ema take its address (workspace + ..._err_offset()).
  * replaces: autograd of attn.py:82. */
-int od_flash_attn_bwd_fused_ws_bytes(int B, int H, int L, long* total_out, long* zero_out);
+int od_flash_attn_bwd_fused_ws_bytes(int dtype, int B, int H, int L, long* total_out, long* zero_out);
 int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
                             const void* dout, int lddo, const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
                             int B, int H, int L, int hd, float scale, int q_prescaled, void* ws, long ws_bytes, void* stream);

@@ -449,6 +449,54 @@ def gen_train_bf16(out_dir, name, d: O.Dims, B, L, seed, store_full):
           "gnorm f32", float(fx["f32.grad_norm"]), "bf16", float(fx["bf16.grad_norm"]))
 
 
+def gen_train_f16(out_dir, name, d: O.Dims, B, L, seed, store_full):
+    """The reference's training loss and gradients under `precision: 16-mixed` (the fp16 option of the trainer key model.yml:12;
+    BASELINE configs[4] "attention in fp16"): DiffusionTrainer.forward + backward inside torch.autocast(float16), the loss multiplied by a
+    GradScaler-style power of two before backward (starting at 2^16 and halved until every gradient is finite, as Lightning's scaler
+    does over its first steps) and the gradients divided by it again — next to the fp32 and bf16-autocast results of the same weights /
+    batch / noise.  The HIP step with attn_dtype = float16 (bf16 compute around a half-operand attention core) is held to the fp16 run
+    within the reference's own bf16 noise."""
+    import osu_dreamer.models.diffusion.train as train_mod
+    P = O.init_params(d, seed=seed)
+    data = O.synthetic_batch(d, B, L, seed=seed + 1)
+    fx = {"dims": np.array(list(d.to_dict().values())), "B": B, "L": L, "seed": seed}
+    u01 = torch.special.ndtr(torch.logit(data["t"].double())).float()
+    u_eff = (torch.zeros(B) + u01 * B) / B
+    fx["t_used"] = torch.special.ndtri(u_eff.clamp(1e-6, 1 - 1e-6)).sigmoid()
+    for tag, mk_ctx in (("f32", lambda: torch.autocast("cpu", enabled=False)), ("bf16", lambda: torch.autocast("cpu", dtype=torch.bfloat16)),
+                        ("f16", lambda: torch.autocast("cpu", dtype=torch.float16))):
+        scale = 65536.0 if tag == "f16" else 1.0
+        while True:
+            tr = _ref_trainer(d, P)
+            with _FixedNoise(train_mod, u01, data["x0"]):
+                tr.zero_grad()
+                with mk_ctx():
+                    loss, logs = tr(tr.diffusion, data["h"], data["z"], data["s"], torch.zeros(B, 5))
+            (loss * scale).backward()
+            grads = {k: (p.grad.detach().float().clone() / scale if p.grad is not None else torch.zeros_like(p))
+                     for k, p in tr.diffusion.named_parameters()}
+            if all(bool(torch.isfinite(g).all()) for g in grads.values()) or scale <= 1.0:
+                break
+            scale /= 2
+        fx[f"{tag}.loss_scale"] = scale
+        fx[f"{tag}.loss"] = loss.detach().float()
+        for k, v in logs.items():
+            fx[f"{tag}.log_{k}"] = v.float()
+        fx[f"{tag}.grad_norm"] = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+        _grad_store(fx, f"{tag}.grad", grads, store_full)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
+    print(name, "loss f32", float(fx["f32.loss"]), "bf16", float(fx["bf16.loss"]), "f16", float(fx["f16.loss"]), "loss scale", fx["f16.loss_scale"],
+          "gnorm f32", float(fx["f32.grad_norm"]), "bf16", float(fx["bf16.grad_norm"]), "f16", float(fx["f16.grad_norm"]))
+
+
+def gen_round5(out_dir):
+    # head_dim 64 (the half-operand attention core exists for it only): a small two-head model with every gradient stored, and the
+    # full-width model at depth 2 (sub-sampled gradients + norms)
+    gen_train_f16(out_dir, "train_f16_small_hd64_b2_l230", O.Dims(global_cond_dim=64, backbone_dim=128, n_heads=2, head_dim=64, depth=2, expand=2,
+                                                                  radius=1, u_head_dim=16), B=2, L=230, seed=1500, store_full=True)
+    gen_train_f16(out_dir, "train_f16_full_d2_b2_l96", O.Dims(depth=2), B=2, L=96, seed=1600, store_full=False)
+
+
 def gen_validation(out_dir, name, d: O.Dims, val_batches, l, seed):
     """The reference's `validation_step` (train.py:128-139): one full map (1, C, l) cut into `val_batches` segments,
     loss under no_grad with the EMA weights.  The EMA copy is given DIFFERENT weights from the live model so that a
@@ -603,6 +651,9 @@ def main():
         return
     if os.environ.get("GOLDEN_ONLY") == "round3":
         gen_round3(out_dir)
+        return
+    if os.environ.get("GOLDEN_ONLY") == "round5":
+        gen_round5(out_dir)
         return
     gen_lr(out_dir)
     gen_ops(out_dir)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "osu_dreamer_hip.h")
 DEFAULT_SO = os.environ.get("OSU_DREAMER_HIP_LIB", os.path.join(_HERE, "libosudreamer_hip.so"))
 
-OD_F32, OD_BF16, OD_F32X3, OD_F32X3W = 0, 1, 2, 3
+OD_F32, OD_BF16, OD_F32X3, OD_F32X3W, OD_F16 = 0, 1, 2, 3, 4
 OD_EPI_NONE, OD_EPI_SILU = 0, 1
 OD_ACT_NONE, OD_ACT_SILU = 0, 1
 

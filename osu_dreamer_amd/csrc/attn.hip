@@ -480,8 +480,17 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd_x3p_kernel(const float* 
 // partial row sum (needed anyway) doubles as the overflow guard — only if a partial sum leaves [0, 2^OD_FWD32_GUARD) does the
 // wave take the exact path (true row max, reference raised, O and l rescaled, p recomputed).
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ f32x16_t od_mma32(s16x8 a, s16x8 b, f32x16_t c) {
+// TA = operand type tag: bf16_t, or f16_t (IEEE half operands: "attention in fp16", v_mfma_f32_32x32x16_f16)
+template <class TA> __device__ __forceinline__ f32x16_t od_mma32(s16x8 a, s16x8 b, f32x16_t c);
+template <> __device__ __forceinline__ f32x16_t od_mma32<bf16_t>(s16x8 a, s16x8 b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16_t od_mma32<f16_t>(s16x8 a, s16x8 b, f32x16_t c) {
+#if defined(OD_EMU)
+    return emu::mfma_32x32x16_f16(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(od_h8_t, a), __builtin_bit_cast(od_h8_t, b), c, 0, 0, 0);
+#endif
 }
 #ifndef OD_FWD32_GUARD
 #define OD_FWD32_GUARD 16384.0f
@@ -490,7 +499,7 @@ __device__ __forceinline__ f32x16_t od_mma32(s16x8 a, s16x8 b, f32x16_t c) {
 #ifndef OD_FWD32_OCC2
 #define OD_FWD32_OCC2 2     // waves per SIMD asked of the register allocator at 64 queries per wave
 #endif
-template <int NW, int NQB, bool PRE>
+template <int NW, int NQB, bool PRE, class TA = bf16_t>
 __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash_fwd32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                                  const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
                                                                  float* __restrict__ lse, int B, int H, int L, float scale) {
@@ -574,9 +583,9 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
             for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
                 for (int qi = 0; qi < NQB; qi++) {
-                    sa[qi][kb] = od_mma32(fk[kb][0], fq[qi][0], minit[qi]);
+                    sa[qi][kb] = od_mma32<TA>(fk[kb][0], fq[qi][0], minit[qi]);
 #pragma unroll
-                    for (int s4 = 1; s4 < 4; s4++) sa[qi][kb] = od_mma32(fk[kb][s4], fq[qi][s4], sa[qi][kb]);
+                    for (int s4 = 1; s4 < 4; s4++) sa[qi][kb] = od_mma32<TA>(fk[kb][s4], fq[qi][s4], sa[qi][kb]);
                     if constexpr (!PRE) sa[qi][kb] = sa[qi][kb] * c + minit[qi] * (1.f - c);    // (q.k) c - reference
                     if constexpr (MASKED) {    // ragged last tile only: keys >= L
 #pragma unroll
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
                         for (int jj = 0; jj < 4; jj++) {
                             const float p0 = od_exp2(sa[qi][kb][8 * sl + 2 * jj]), p1 = od_exp2(sa[qi][kb][8 * sl + 2 * jj + 1]);
                             acc0 += p0; acc1 += p1;
-                            w[jj] = od_pack_bf2(p0, p1);
+                            w[jj] = od_pack2<TA>(p0, p1);
                         }
                         fp[qi][kb][sl] = __builtin_bit_cast(s16x8, w);
                     }
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
                     fv[0] = a0[0]; fv[1] = a0[1]; fv[2] = a0[2]; fv[3] = a0[3];
                     fv[4] = a1[0]; fv[5] = a1[1]; fv[6] = a1[2]; fv[7] = a1[3];
 #pragma unroll
-                    for (int qi = 0; qi < NQB; qi++) oacc[qi][db] = od_mma32(fv, fp[qi][kb][sl], oacc[qi][db]);
+                    for (int qi = 0; qi < NQB; qi++) oacc[qi][db] = od_mma32<TA>(fv, fp[qi][kb][sl], oacc[qi][db]);
                 }
         OD_WAIT_VMCNT(0);           // this wave's pieces of the next tile have landed (the asm DMA is invisible to hipcc's waits)
         __syncthreads();
@@ -1060,6 +1069,15 @@ struct AttnAux {
 template <class T, int HD, bool PRE>
 int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, float* lse, int B,
                int H, int L, float scale, hipStream_t st) {
+    if constexpr (std::is_same<T, f16_t>::value) {          // half operands: q, k, v are IEEE half, o is written as bf16 (head_dim 64 only)
+        static_assert(HD == 64, "the half-operand forward exists for head_dim 64");
+        constexpr int NW = 4, NQB = OD_FWD32_NQB;
+        const int grid = attn_grid((L + NW * NQB * 32 - 1) / (NW * NQB * 32), B * H);
+        OD_LAUNCH_DYN((flash_fwd32_kernel<NW, NQB, PRE, f16_t>), dim3(grid), dim3(64 * NW), (4 * Stage<bf16_t, HD>::BYTES), st, (const bf16_t*)q, ldq,
+                      (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L, scale);
+        OD_CHECK_LAUNCH();
+        return 0;
+    } else {
     if constexpr (OD_FWD32 && std::is_same<T, bf16_t>::value && HD == 64) {
         constexpr int NW = 4, NQB = OD_FWD32_NQB;
         const int grid = attn_grid((L + NW * NQB * 32 - 1) / (NW * NQB * 32), B * H);
@@ -1094,6 +1112,7 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
               (T*)o, ldo, lse, B, H, L, scale);
     OD_CHECK_LAUNCH();
     return 0;
+    }
 }
 
 template <class T, int HD, int NK, int NQ, bool PRE>
@@ -1140,6 +1159,7 @@ extern "C" int od_flash_attn_fwd(int dtype, const void* q, int ldq, const void* 
 #define FWD(TT, HDV) (q_prescaled ? launch_fwd<TT, HDV, true>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st) \
                                   : launch_fwd<TT, HDV, false>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, L, scale, st))
     if (dtype == OD_BF16 && hd == 64) return FWD(bf16_t, 64);
+    if (dtype == OD_F16 && hd == 64) return FWD(f16_t, 64);
     if (dtype == OD_BF16 && hd == 32) return FWD(bf16_t, 32);
     if (dtype == OD_F32 && hd == 64) return FWD(float, 64);
     if (dtype == OD_F32 && hd == 32) return FWD(float, 32);

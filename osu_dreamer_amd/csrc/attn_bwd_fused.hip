@@ -180,14 +180,74 @@ __global__ __launch_bounds__(256) void fb_prep_kernel(const bf16_t* __restrict__
     }
 }
 
-template <bool PRE>
+// ---- "attention in fp16": dout arrives as bf16 like every other activation gradient and is STAGED as half, scaled by a power of two
+// largest |dout| of the tensor (bit pattern of a non-negative float: unsigned compare = float compare); *amax_bits is zero before the launch
+__global__ __launch_bounds__(256) void fb_amax_kernel(const bf16_t* __restrict__ dout, int lddo, long M, int dh, unsigned* __restrict__ amax_bits) {
+    const int nch = dh / 8;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M * nch; i += (long)gridDim.x * 256) {
+        float d[8];
+        od_ld8(dout + (i / nch) * lddo + (i % nch) * 8, d);
+#pragma unroll
+        for (int e = 0; e < 8; e++) m = fmaxf(m, fabsf(d[e]));
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, fb_f2u(m));
+}
+// the power of two that brings amax into (32, 64]: products with v (|v| ~ 1-10, 64 terms) and with P <= 1 then stay far below half's 65504,
+// and 2^-24 (half's smallest subnormal) is 2^-30 of the largest element.  1 for an all-zero or non-finite tensor.
+__device__ __forceinline__ float fb_dscale_of(unsigned amax_bits) {
+    const unsigned e = (amax_bits >> 23) & 0xffu;
+    if (amax_bits == 0u || e == 0u || e == 0xffu) return 1.0f;
+    const int ex = (int)e - 127 + ((amax_bits & 0x7fffffu) ? 1 : 0);      // ceil(log2(amax))
+    int se = 6 - ex; se = se < -100 ? -100 : se > 100 ? 100 : se;
+    return fb_u2f((unsigned)(se + 127) << 23);
+}
+// fb_prep_kernel + the staged copy: nl = -lse', nd = -dscale * delta, do16 = half(dscale * dout)
+__global__ __launch_bounds__(256) void fb_prep_f16_kernel(const bf16_t* __restrict__ o, int ldo, const bf16_t* __restrict__ dout, int lddo,
+                                                          const float* __restrict__ lse, float* __restrict__ nl, float* __restrict__ nd,
+                                                          f16_t* __restrict__ do16, int ldd16, const unsigned* __restrict__ amax_bits,
+                                                          float* __restrict__ dscale_out, int B, int H, int L, float inv_scale) {
+    const float ds = fb_dscale_of(amax_bits[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) dscale_out[0] = ds;
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)B * L) return;
+    const int b = (int)(m / L), l = (int)(m % L);
+    const int nch = H * 8;
+    for (int it = 0; it * 64 < nch; it++) {
+        const int qd = it * 64 + lane;
+        const bool act = qd < nch;
+        float s = 0.f;
+        if (act) {
+            float a[8], d[8];
+            od_ld8(o + m * ldo + qd * 8, a); od_ld8(dout + m * lddo + qd * 8, d);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { s += a[e] * d[e]; d[e] *= ds; }
+            od_st8(do16 + m * ldd16 + qd * 8, d);
+        }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (act && (qd & 7) == 0) {
+            const size_t i = ((size_t)b * H + (qd >> 3)) * L + l;
+            nd[i] = -s * ds;
+            nl[i] = -lse[i] * inv_scale;
+        }
+    }
+}
+
+// TA = the MFMA operand type: bf16_t, or f16_t ("attention in fp16": q, k, v, dout point at IEEE-half data, P and dS are rounded to half, the
+// five products are v_mfma_f32_16x16x32_f16; dq, dk, dv are written as bf16 either way — they are rounded accumulators).  In the half form dout
+// is the copy fb_prep_kernel staged, multiplied by the power of two `dscale` that brings the tensor's largest magnitude into (32, 64] —
+// gradients of a mean-reduced loss are ~1e-6 and would vanish in half; the outputs are divided by it again.
+template <bool PRE, class TA>
 __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                                  const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int lddo,
                                                                  const float* __restrict__ nl, const float* __restrict__ nd,
                                                                  bf16_t* __restrict__ dq, int lddq, bf16_t* __restrict__ dk, int lddk,
                                                                  bf16_t* __restrict__ dv, int lddv, float* __restrict__ run,
                                                                  FbSync* __restrict__ sync, int B, int H, int L, float scale,
-                                                                 unsigned wait_ticks) {
+                                                                 unsigned wait_ticks, const float* __restrict__ dscale_p) {
     constexpr int NK = FB_NK, KB = FB_KB;
     OD_DYN_SMEM(smem);
     int* const s_job = (int*)(smem + FB_KST + FB_DS);
@@ -206,7 +266,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             return;
         }
     }
-    const float c = scale * FB_LOG2E, out_scale = PRE ? FB_LN2 : scale;
+    const float inv_ds = std::is_same<TA, f16_t>::value ? 1.0f / dscale_p[0] : 1.0f;      // (a power of two: exact)
+    const float c = scale * FB_LOG2E, out_scale = (PRE ? FB_LN2 : scale) * inv_ds;
     int my_jobs = 0;
 
     // Jobs.  The next job's number is drawn by thread 0 at the START of a job's last query tile and left in LDS in front of that tile's barrier:
@@ -244,14 +305,14 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             // =================================================================== key waves
             if (FB_PRIO) __builtin_amdgcn_s_setprio(FB_PRIO);
             const int key0 = kblk * KB + wave * NK * 16;
-            od_frag<bf16_t> fk[NK][2], fv[NK][2];
+            od_frag<TA> fk[NK][2], fv[NK][2];
 #pragma unroll
             for (int ki = 0; ki < NK; ki++) {
                 int row = key0 + ki * 16 + x; row = row < L ? row : L - 1;
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
-                    od_frag_load(fk[ki][s], kb_ + (size_t)row * ldk + s * 32 + g * 8);
-                    od_frag_load(fv[ki][s], vb + (size_t)row * ldv + s * 32 + g * 8);
+                    od_frag_load(fk[ki][s], (const TA*)(kb_ + (size_t)row * ldk + s * 32 + g * 8));
+                    od_frag_load(fv[ki][s], (const TA*)(vb + (size_t)row * ldv + s * 32 + g * 8));
                 }
             }
             f32x4 dkacc[NK][4], dvacc[NK][4];
@@ -280,11 +341,11 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                 // their MFMAs before the next half's are formed — half the live fragment registers of a whole-tile pass
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    od_frag<bf16_t> fp[NK], fds[NK];
+                    od_frag<TA> fp[NK], fds[NK];
 #pragma unroll
                     for (int th = 0; th < 2; th++) {
                         const int t4 = 2 * u + th;
-                        od_frag<bf16_t> fqr[2], fdo[2];
+                        od_frag<TA> fqr[2], fdo[2];
 #pragma unroll
                         for (int s = 0; s < 2; s++) {
                             if ((FB_X & 1024) && t4) { fqr[s] = fk[0][s]; fdo[s] = fv[0][s]; continue; }
@@ -322,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                     // of the MFMAs were fully exposed (1.5 ms per call), one between each group of six MFMAs hides behind them.
                     // The transposed fragments of feature tile dt + 1 are read BEFORE the six MFMAs of tile dt: read -> wait -> MFMA per tile left the
                     // LDS round trip of the transpose reads exposed eight times per query tile (this wave is alone with its MFMAs on the SIMD).
-                    od_frag<bf16_t> fot[2], fqt[2];
+                    od_frag<TA> fot[2], fqt[2];
                     frag_cols<128, 128>(fot[0], tO, tO, 0, x, u, g);
                     frag_cols<128, 128>(fqt[0], tQ, tQ, 0, x, u, g);
 #pragma unroll
@@ -359,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                     bf16_t* dvr = dv + ((size_t)b * L + row) * lddv + h * 64;
 #pragma unroll
                     for (int dt = 0; dt < 4; dt++) {
-                        const f32x4 a = dkacc[ki][dt] * out_scale, e = dvacc[ki][dt];
+                        const f32x4 a = dkacc[ki][dt] * out_scale, e = dvacc[ki][dt] * inv_ds;
                         u32x2 w0, w1;
                         w0[0] = od_pack_bf2(a[0], a[1]); w0[1] = od_pack_bf2(a[2], a[3]);
                         w1[0] = od_pack_bf2(e[0], e[1]); w1[1] = od_pack_bf2(e[2], e[3]);
@@ -383,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             auto ji_of = [](int a) FB_INLINE { return FB_SPLIT == 0 ? 0 : FB_SPLIT == 1 ? a : a >> 1; };
             auto gi_of = [](int a) FB_INLINE { return FB_SPLIT == 0 ? a : FB_SPLIT == 1 ? 0 : a & 1; };
             const int j0 = FB_SPLIT == 0 ? hh : FB_SPLIT == 1 ? 0 : 2 * (hh & 1), G0 = FB_SPLIT == 0 ? 0 : FB_SPLIT == 1 ? hh : 2 * (hh >> 1);
-            od_frag<bf16_t> fkt[NJ][6];                                  // filled from the staged K rows after the job's first barrier (below)
+            od_frag<TA> fkt[NJ][6];                                  // filled from the staged K rows after the job's first barrier (below)
             // Q / dO tile streaming: piece = 8 rows x 128 B; this wave moves pieces hh and hh + 4 of both tiles; waves 0 / 1 also move the
             // 64 start values (-lse', -delta).  Rows past L lie beyond the descriptors and read as zero.
             const od_srd_t rq = od_make_srd(qb, (unsigned)(((size_t)(L - 1) * ldq + 64) * 2));
@@ -489,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                 for (int s = 0; s < 6; s++) {
                     if (s + 1 < 6) rd(s + 1, f[(s + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);                   // keep the reads of the next slab ABOVE this slab's MFMAs
-                    od_frag<bf16_t> fb[NG];
+                    od_frag<TA> fb[NG];
 #pragma unroll
                     for (int gi = 0; gi < NG; gi++) {
                         const s16x4 b0 = f[s & 1][gi][0], b1 = f[s & 1][gi][1];
@@ -721,15 +782,17 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
 }
 
 inline size_t fb_align(size_t n) { return (n + 255) & ~(size_t)255; }
-struct FbLayout { size_t sync, nl, nd, run, total; };
-inline FbLayout fb_layout(int B, int H, int L) {
+struct FbLayout { size_t sync, nl, nd, run, aux, do16, total; };
+inline FbLayout fb_layout(int B, int H, int L, bool f16 = false) {
     const size_t BH = (size_t)B * H, nqt = (size_t)(L + 63) / 64;
     FbLayout l;
     l.sync = 0;
     l.run = fb_align(sizeof(FbSync));
     l.nl = l.run + fb_align((size_t)8 * FB_SLOTS * nqt * FB_RUN_TILE * sizeof(float));      // [0, nl): what has to be zero before the first launch
     l.nd = l.nl + fb_align(BH * L * sizeof(float));
-    l.total = l.nd + fb_align(BH * L * sizeof(float));
+    l.aux = l.nd + fb_align(BH * L * sizeof(float));                // half form: [0] = amax bits of dout, [1] = dscale
+    l.do16 = l.aux + 256;                                            // half form: the staged dout, [B L][H 64]
+    l.total = f16 ? l.do16 + fb_align(BH * L * 64 * sizeof(unsigned short)) : l.aux;
     return l;
 }
 
@@ -755,9 +818,9 @@ inline unsigned fb_wait_ticks() {
 
 // Bytes of the caller-owned workspace of od_flash_attn_bwd_fused (*total_out) and of its head (*zero_out: the control block and the running
 // tiles), which must be ZERO before the first launch (the start values behind it are written by every launch before they are read).
-extern "C" int od_flash_attn_bwd_fused_ws_bytes(int B, int H, int L, long* total_out, long* zero_out) {
-    if (B <= 0 || H <= 0 || L <= 0 || !total_out || !zero_out) return OD_ERR_ARG;
-    const FbLayout lay = fb_layout(B, H, L);
+extern "C" int od_flash_attn_bwd_fused_ws_bytes(int dtype, int B, int H, int L, long* total_out, long* zero_out) {
+    if (B <= 0 || H <= 0 || L <= 0 || !total_out || !zero_out || (dtype != OD_BF16 && dtype != OD_F16)) return OD_ERR_ARG;
+    const FbLayout lay = fb_layout(B, H, L, dtype == OD_F16);
     *total_out = (long)lay.total;
     *zero_out = (long)lay.nl;
     return 0;
@@ -783,10 +846,11 @@ extern "C" int od_flash_attn_bwd_fused_prof(void* ws, long* out16) {
 extern "C" int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo,
                                        const void* dout, int lddo, const float* lse, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv,
                                        int B, int H, int L, int hd, float scale, int q_prescaled, void* ws, long ws_bytes, void* stream) {
-    if (dtype != OD_BF16 || hd != 64) return OD_ERR_UNSUPPORTED;
+    if ((dtype != OD_BF16 && dtype != OD_F16) || hd != 64) return OD_ERR_UNSUPPORTED;
     if (!ws || B <= 0 || H <= 0 || L <= 0) return OD_ERR_ARG;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) return OD_ERR_ALIGN;
-    const FbLayout lay = fb_layout(B, H, L);
+    const bool f16 = dtype == OD_F16;
+    const FbLayout lay = fb_layout(B, H, L, f16);
     if (ws_bytes < (long)lay.total) return OD_ERR_ARG;
     if (((size_t)L * (size_t)(ldq > lddo ? (ldq > ldk ? ldq : ldk) : (lddo > ldk ? lddo : ldk))) * 2 >= 0xffffffffull) return OD_ERR_UNSUPPORTED;      // 32-bit buffer offsets
     hipStream_t st = (hipStream_t)stream;
@@ -794,14 +858,36 @@ extern "C" int od_flash_attn_bwd_fused(int dtype, const void* q, int ldq, const 
     float* nl = (float*)(w + lay.nl);
     float* nd = (float*)(w + lay.nd);
     const long M = (long)B * L;
-    OD_LAUNCH(fb_prep_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, nl, nd, B, H, L,
-              q_prescaled ? FB_LOG2E : 1.0f / scale);
+    const float inv_scale = q_prescaled ? FB_LOG2E : 1.0f / scale;
+    const float* dscale_p = nullptr;
+    if (f16) {
+        // half form: amax of dout -> power-of-two scale -> staged half copy (dout itself is bf16, like every other activation gradient)
+        unsigned* amax = (unsigned*)(w + lay.aux);
+        float* dsc = (float*)(w + lay.aux) + 1;
+        f16_t* do16 = (f16_t*)(w + lay.do16);
+#if defined(OD_EMU)
+        *amax = 0u;
+#else
+        if (hipMemsetAsync(amax, 0, sizeof(unsigned), st) != hipSuccess) return OD_ERR_ARG;
+#endif
+        OD_LAUNCH(fb_amax_kernel, dim3(2048), dim3(256), 0, st, (const bf16_t*)dout, lddo, M, H * 64, amax);
+        OD_LAUNCH(fb_prep_f16_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, nl, nd,
+                  do16, H * 64, (const unsigned*)amax, dsc, B, H, L, inv_scale);
+        dout = do16; lddo = H * 64; dscale_p = dsc;
+    } else
+        OD_LAUNCH(fb_prep_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, lse, nl, nd, B, H, L, inv_scale);
     const int grid = od_num_cus();
 #define FB_ARGS dim3(grid), dim3(512), FB_SMEM, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)dout, lddo, \
-        (const float*)nl, (const float*)nd, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, (float*)(w + lay.run), (FbSync*)(w + lay.sync), B, H, L, scale, fb_wait_ticks()
+        (const float*)nl, (const float*)nd, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, (float*)(w + lay.run), (FbSync*)(w + lay.sync), B, H, L, scale, \
+        fb_wait_ticks(), dscale_p
 #define FB_LAUNCH_X(...) OD_LAUNCH_DYN(__VA_ARGS__)      /* lets the argument-list macro expand first */
-    if (q_prescaled) FB_LAUNCH_X((flash_bwd_fused_kernel<true>), FB_ARGS);
-    else FB_LAUNCH_X((flash_bwd_fused_kernel<false>), FB_ARGS);
+    if (f16) {
+        if (q_prescaled) FB_LAUNCH_X((flash_bwd_fused_kernel<true, f16_t>), FB_ARGS);
+        else FB_LAUNCH_X((flash_bwd_fused_kernel<false, f16_t>), FB_ARGS);
+    } else {
+        if (q_prescaled) FB_LAUNCH_X((flash_bwd_fused_kernel<true, bf16_t>), FB_ARGS);
+        else FB_LAUNCH_X((flash_bwd_fused_kernel<false, bf16_t>), FB_ARGS);
+    }
 #undef FB_LAUNCH_X
 #undef FB_ARGS
     OD_CHECK_LAUNCH();

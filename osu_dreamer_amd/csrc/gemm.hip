@@ -104,6 +104,8 @@ struct RopeEpi {
     int L, dh, hd, n_rope; float eps, q_scale;               // dh = H*hd (q columns), n_rope = 2*dh; q outputs * q_scale
     void* qk_out; int ldqk;                                  // large-M kernel only: normed + rotated q, k go HERE (C keeps the pre-norm
                                                              // values the backward needs); NULL: they replace C[:, :n_rope]
+    int f16;                                                 // with qk_out, 4-wave kernel only: qk_out and the v columns of C (>= n_rope) are
+                                                             // written as IEEE half ("attention in fp16"); C's q / k columns stay bf16
 };
 constexpr int OD_EPI_QKROPE = 2;
 
@@ -760,17 +762,22 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                     const int hc0 = n0 + wn * 128 + 64 * hq;
                     const bool roped = roped2[hq];
                     const bool valid = gm < M && hc0 < N;
-                    float v[2][8];
+                    float v[2][8], raw[2][8];
 #pragma unroll
                     for (int p = 0; p < 2; p++) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            v[p][r] = od_round_to<T>(acc[4 * hq + 2 * p][j][r]);
-                            v[p][4 + r] = od_round_to<T>(acc[4 * hq + 2 * p + 1][j][r]);
+                            raw[p][r] = acc[4 * hq + 2 * p][j][r]; raw[p][4 + r] = acc[4 * hq + 2 * p + 1][j][r];
+                            v[p][r] = od_round_to<T>(raw[p][r]);
+                            v[p][4 + r] = od_round_to<T>(raw[p][4 + r]);
                         }
                         acc[4 * hq + 2 * p][j] = bv[4 * hq + 2 * p]; acc[4 * hq + 2 * p + 1][j] = bv[4 * hq + 2 * p + 1];
                     }
                     T* crow = C + (size_t)(valid ? gm : 0) * ldc + hc0 + 8 * g;
+                    if (!roped && rp.f16) {                   // v as IEEE half, straight from the accumulators (no bf16 rounding in between)
+                        if (valid) { od_st8((f16_t*)crow, raw[0]); od_st8((f16_t*)crow + 32, raw[1]); }
+                        continue;
+                    }
                     if (!roped || qk) {
                         if (valid) {
                             if (c_nt) { od_st8_nt(crow, v[0]); od_st8_nt(crow + 32, v[1]); }
@@ -793,7 +800,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                     }
                     if (valid && !(OD_W4Q_X & 4)) {
                         T* dst = qk ? qk + (size_t)gm * rp.ldqk + hc0 + 8 * g : crow;
-                        if ((OD_W4Q_X & 2) && qk) { od_st8_nt(dst, o0); od_st8_nt(dst + 32, o1); }
+                        if (rp.f16 && qk) { od_st8((f16_t*)dst, o0); od_st8((f16_t*)dst + 32, o1); }
+                        else if ((OD_W4Q_X & 2) && qk) { od_st8_nt(dst, o0); od_st8_nt(dst + 32, o1); }
                         else { od_st8(dst, o0); od_st8(dst + 32, o1); }
                     }
                 }
@@ -1190,7 +1198,7 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
             static const int w4 = od_env_int("OD_NT_W4", 1);
             static const int w4_min_k = od_env_int("OD_NT_W4_MIN_K", 0);
             static const int w4_rope = od_env_int("OD_NT_W4_QKROPE", 1);      // (0: the 8-wave kernel's norm + RoPE epilogue; A/B)
-            if (w4 && (epi != OD_EPI_QKROPE || w4_rope) && !accumulate && K >= w4_min_k && K % 128 == 0) {
+            if ((rp.f16 || (w4 && (epi != OD_EPI_QKROPE || w4_rope) && K >= w4_min_k)) && !accumulate && K % 128 == 0) {
                 int pgrid = od_num_cus() & ~7;                 // persistent: one workgroup per CU, a multiple of 8 (block b runs on XCD b % 8)
                 pgrid = pgrid < 8 ? 8 : pgrid;
                 if (epi == OD_EPI_QKROPE)
@@ -1326,7 +1334,7 @@ extern "C" int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* 
     if (lda % ch || ldw % ch || K % ch || N % 8 || ldc % 8) return OD_ERR_ALIGN;
     const int n_rope = 2 * H * hd;
     if ((hd != 32 && hd != 64) || n_rope % 128 || n_rope > N) return OD_ERR_UNSUPPORTED;
-    const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps, q_scale, nullptr, 0};
+    const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps, q_scale, nullptr, 0, 0};
     if (dtype == OD_BF16)
         return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
     if (dtype == OD_F32)
@@ -1340,22 +1348,46 @@ extern "C" int od_gemm_nt_qkrope(int dtype, const void* A, int lda, const void* 
     return OD_ERR_ARG;
 }
 
+namespace {
+// columns [c0, c0 + ncols) of a bf16 matrix re-encoded as IEEE half in place (the small-shape path of "attention in fp16": v)
+__global__ __launch_bounds__(256) void cast_bf16_to_f16_kernel(bf16_t* __restrict__ p, int ld, long M, int ncols) {
+    const int nch = ncols / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M * nch; i += (long)gridDim.x * 256) {
+        bf16_t* a = p + (i / nch) * ld + (i % nch) * 8;
+        float v[8];
+        od_ld8(a, v);
+        od_st8((f16_t*)a, v);
+    }
+}
+}  // namespace
+
 extern "C" int od_gemm_nt_qkrope_split(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc,
-                                       void* qk_out, int ldqk, int M, int N, int K, const float* wq, const float* wk, const float* table,
-                                       int L, int H, int hd, float eps, float q_scale, void* stream) {
+                                       void* qk_out, int ldqk, int qk_dtype, int M, int N, int K, const float* wq, const float* wk,
+                                       const float* table, int L, int H, int hd, float eps, float q_scale, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !bias || !wq || !wk || !table || L <= 0 || !qk_out || M % L) return OD_ERR_ARG;
     const int ch = dtype == OD_BF16 ? 8 : 4;
     if (lda % ch || ldw % ch || K % ch || N % 8 || ldc % 8 || ldqk % 8) return OD_ERR_ALIGN;
     const int n_rope = 2 * H * hd;
     if (n_rope > N) return OD_ERR_UNSUPPORTED;
+    // qk_dtype = OD_F16 ("attention in fp16"): qk_out and the v columns of C (from 2*H*hd on) hold IEEE half; C's q / k columns — the
+    // pre-norm values the norm's backward reads — stay bf16.  bf16 GEMM, head_dim 64 only.
+    const bool f16 = qk_dtype == OD_F16;
+    if (!f16 && qk_dtype != dtype && !((dtype == OD_F32X3 || dtype == OD_F32X3W) && qk_dtype == OD_F32)) return OD_ERR_ARG;
+    if (f16 && (dtype != OD_BF16 || hd != 64 || (N - n_rope) % 8)) return OD_ERR_UNSUPPORTED;
     // one launch where the large-M kernel's epilogue applies (bf16, head_dim 64, M >= OD_GEMM_BIG_MIN_M, K a multiple of 64); otherwise the two
     // kernels it replaces
-    if (dtype == OD_BF16 && hd == 64 && M >= OD_GEMM_BIG_MIN_M && K % 64 == 0 && N % 64 == 0 && N >= 256) {
-        const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps, q_scale, qk_out, ldqk};
+    if (dtype == OD_BF16 && hd == 64 && M >= OD_GEMM_BIG_MIN_M && K % 64 == 0 && N % 64 == 0 && N >= 256 && (!f16 || K % 128 == 0)) {
+        const RopeEpi rp{wq, wk, table, L, H * hd, hd, n_rope, eps, q_scale, qk_out, ldqk, f16 ? 1 : 0};
         return launch_nt<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, bias, (bf16_t*)C, ldc, M, N, K, OD_EPI_QKROPE, 0, (hipStream_t)stream, rp);
     }
     if (int rc = od_gemm_nt(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, OD_EPI_NONE, 0, stream)) return rc;
-    return od_qk_norm_rope((dtype == OD_F32X3 || dtype == OD_F32X3W) ? OD_F32 : dtype, C, ldc, wq, wk, table, qk_out, ldqk, M / L, L, H, hd, eps, q_scale, stream);
+    if (int rc = od_qk_norm_rope(f16 ? OD_F16 : (dtype == OD_F32X3 || dtype == OD_F32X3W) ? OD_F32 : dtype, C, ldc, wq, wk, table, qk_out, ldqk, M / L, L, H, hd, eps,
+                                 q_scale, stream)) return rc;
+    if (f16 && N > n_rope) {
+        OD_LAUNCH(cast_bf16_to_f16_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (bf16_t*)C + n_rope, ldc, (long)M, N - n_rope);
+        OD_CHECK_LAUNCH();
+    }
+    return 0;
 }
 
 extern "C" int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M,

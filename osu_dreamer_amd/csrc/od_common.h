@@ -61,6 +61,23 @@ __device__ __forceinline__ uint32_t od_pack_bf2(float lo, float hi) {
 __device__ __forceinline__ float od_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif
 
+// IEEE half (OD_F16): the operand type of the attention MFMAs when the host asks for "attention in fp16" (BASELINE configs[4]; Lightning's
+// precision: 16-mixed of the reference's trainer, model.yml:12).  A distinct type (bf16_t is a bare unsigned short): q, k, v, the staged dO
+// and the in-kernel P / dS are half, everything around the attention core stays bf16.  Round-to-nearest-even both ways.
+struct f16_t { unsigned short bits; };
+#if defined(OD_EMU)
+__device__ __forceinline__ float od_h2f(f16_t h) { return emu::f16_to_f32(h.bits); }
+__device__ __forceinline__ f16_t od_f2h(float f) { return f16_t{emu::f32_to_f16(f)}; }
+#else
+__device__ __forceinline__ float od_h2f(f16_t h) { return (float)__builtin_bit_cast(_Float16, h.bits); }
+__device__ __forceinline__ f16_t od_f2h(float f) { return f16_t{__builtin_bit_cast(unsigned short, (_Float16)f)}; }
+#endif
+__device__ __forceinline__ uint32_t od_pack_h2(float lo, float hi) { return (uint32_t)od_f2h(lo).bits | ((uint32_t)od_f2h(hi).bits << 16); }
+// two floats -> one dword of the 16-bit operand type T
+template <class T> __device__ __forceinline__ uint32_t od_pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t od_pack2<bf16_t>(float lo, float hi) { return od_pack_bf2(lo, hi); }
+template <> __device__ __forceinline__ uint32_t od_pack2<f16_t>(float lo, float hi) { return od_pack_h2(lo, hi); }
+
 // compute-type tag: fp32 storage whose MFMA products run as 3 bf16 MFMAs (OD_F32X3, inference only)
 struct f32x3_t { float x; };
 // same, for GEMMs whose WEIGHT operand was split into (hi, lo) bf16 halves once at pack time (od_pack_weight with OD_F32X3W): the
@@ -81,11 +98,16 @@ template <> struct od_t<bf16_t> {
     static __device__ __forceinline__ float ld(const bf16_t* p) { return od_bf2f(*p); }
     static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = od_f2bf(v); }
 };
+template <> struct od_t<f16_t> {
+    static __device__ __forceinline__ float ld(const f16_t* p) { return od_h2f(*p); }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = od_f2h(v); }
+};
 
 // x as it reads back after a store to T
 template <class T> __device__ __forceinline__ float od_round_to(float x);
 template <> __device__ __forceinline__ float od_round_to<float>(float x) { return x; }
 template <> __device__ __forceinline__ float od_round_to<bf16_t>(float x) { return od_bf2f(od_f2bf(x)); }
+template <> __device__ __forceinline__ float od_round_to<f16_t>(float x) { return od_h2f(od_f2h(x)); }
 template <> __device__ __forceinline__ float od_round_to<f32x3_t>(float x) { return x; }
 template <> __device__ __forceinline__ float od_round_to<f32x3w_t>(float x) { return x; }
 
@@ -116,6 +138,21 @@ __device__ __forceinline__ void od_st8(bf16_t* p, const float (&v)[8]) {
     u32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; i++) r[i] = od_pack_bf2(v[2 * i], v[2 * i + 1]);
+    *(u32x4*)p = r;
+}
+
+__device__ __forceinline__ void od_ld8(const f16_t* p, float (&v)[8]) {
+    u32x4 r = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        v[2 * i] = od_h2f(f16_t{(unsigned short)(r[i] & 0xffffu)});
+        v[2 * i + 1] = od_h2f(f16_t{(unsigned short)(r[i] >> 16)});
+    }
+}
+__device__ __forceinline__ void od_st8(f16_t* p, const float (&v)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = od_pack_h2(v[2 * i], v[2 * i + 1]);
     *(u32x4*)p = r;
 }
 
@@ -185,6 +222,7 @@ __device__ __forceinline__ f32x4 od_mul4s(f32x4 a, float b) {
 // ---------------------------------------------------------------------------------
 template <class T> struct od_frag;
 template <> struct od_frag<bf16_t> { s16x8 v; };
+template <> struct od_frag<f16_t> { s16x8 v; };
 template <> struct od_frag<float> { float v[8]; };
 // f32x3: fp32 in memory, three bf16 MFMAs per product.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
 // (|x - hi - lo| <= 2^-17 |x|);  a.b ~ ahi.bhi + ahi.blo + alo.bhi, accumulated in fp32.
@@ -212,6 +250,7 @@ __device__ __forceinline__ void od_frag_pack(od_frag<f32x3_t>& f, const float (&
 }
 
 __device__ __forceinline__ void od_frag_load(od_frag<bf16_t>& f, const bf16_t* p) { f.v = *(const s16x8*)p; }
+__device__ __forceinline__ void od_frag_load(od_frag<f16_t>& f, const f16_t* p) { f.v = *(const s16x8*)p; }
 __device__ __forceinline__ void od_frag_load(od_frag<float>& f, const float* p) { od_ld8(p, f.v); }
 __device__ __forceinline__ void od_frag_load(od_frag<f32x3_t>& f, const f32x3_t* p) { float x[8]; od_ld8(p, x); od_frag_pack(f, x); }
 __device__ __forceinline__ void od_frag_zero(od_frag<bf16_t>& f) { f.v = (s16x8)(0); }
@@ -225,6 +264,12 @@ __device__ __forceinline__ void od_frag_set4(od_frag<bf16_t>& f, int half, float
     u32x4 w = __builtin_bit_cast(u32x4, f.v);
     w[2 * half] = od_pack_bf2(a, b);
     w[2 * half + 1] = od_pack_bf2(c, d);
+    f.v = __builtin_bit_cast(s16x8, w);
+}
+__device__ __forceinline__ void od_frag_set4(od_frag<f16_t>& f, int half, float a, float b, float c, float d) {
+    u32x4 w = __builtin_bit_cast(u32x4, f.v);
+    w[2 * half] = od_pack_h2(a, b);
+    w[2 * half + 1] = od_pack_h2(c, d);
     f.v = __builtin_bit_cast(s16x8, w);
 }
 __device__ __forceinline__ void od_frag_set4(od_frag<float>& f, int half, float a, float b, float c, float d) {
@@ -254,6 +299,14 @@ __device__ __forceinline__ s16x4 od_lds_tr_read(const bf16_t* p) {
 __device__ __forceinline__ f32x4 od_mma(const od_frag<bf16_t>& a, const od_frag<bf16_t>& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
 }
+#if defined(OD_EMU)
+__device__ __forceinline__ f32x4 od_mma(const od_frag<f16_t>& a, const od_frag<f16_t>& b, f32x4 c) { return emu::mfma_16x16x32_f16(a.v, b.v, c); }
+#else
+typedef _Float16 od_h8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 od_mma(const od_frag<f16_t>& a, const od_frag<f16_t>& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(od_h8_t, a.v), __builtin_bit_cast(od_h8_t, b.v), c, 0, 0, 0);
+}
+#endif
 __device__ __forceinline__ f32x4 od_mma(const od_frag<float>& a, const od_frag<float>& b, f32x4 c) {
 #pragma unroll
     for (int j = 0; j < 8; j++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);

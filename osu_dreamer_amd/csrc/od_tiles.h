@@ -24,6 +24,10 @@ template <int ROWB>
 __device__ __forceinline__ void frag_contig(od_frag<bf16_t>& f, const unsigned char* t, int row, int k0) {
     f.v = *(const s16x8*)(t + tile_off<ROWB>(row, k0 * 2));
 }
+template <int ROWB>
+__device__ __forceinline__ void frag_contig(od_frag<f16_t>& f, const unsigned char* t, int row, int k0) {
+    f.v = *(const s16x8*)(t + tile_off<ROWB>(row, k0 * 2));
+}
 template <int ROWB, class F>
 __device__ __forceinline__ void frag_contig_f32(od_frag<F>& f, const unsigned char* t, int row, int k0) {
     const f32x4 a = *(const f32x4*)(t + tile_off<ROWB>(row, k0 * 4));
@@ -65,6 +69,12 @@ __device__ __forceinline__ void frag_cols(od_frag<bf16_t>& f, const unsigned cha
     const s16x4 b = od_lds_tr_read((const bf16_t*)(t_rm + tile_off<ROWB>(rr + 16, cb)));
     f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
     f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+template <int ROWB, int TROWB>
+__device__ __forceinline__ void frag_cols(od_frag<f16_t>& f, const unsigned char* t_rm, const unsigned char*, int c0, int x, int u, int g) {
+    od_frag<bf16_t> t;                                   // a 16-bit transpose moves bits: the element type does not matter
+    frag_cols<ROWB, TROWB>(t, t_rm, t_rm, c0, x, u, g);
+    f.v = t.v;
 }
 template <int ROWB, int TROWB>
 __device__ __forceinline__ void frag_cols(od_frag<float>& f, const unsigned char*, const unsigned char* t_tr, int c0, int x, int u, int g) {

@@ -465,10 +465,10 @@ __global__ __launch_bounds__(256) void final_proj_bwd_kernel(const T* __restrict
 
 // ------------------------------------------------------------------ q/k RMSNorm(hd) + RoPE
 // lane owns 8 consecutive features of one head; a head spans hd/8 adjacent lanes.
-template <class T>
+template <class T, class TO = T>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const T* __restrict__ qkv, int ldqkv, const float* __restrict__ wq,
                                                            const float* __restrict__ wk, const float* __restrict__ table,
-                                                           T* __restrict__ out, int ldo, int B, int L, int H, int hd, float eps,
+                                                           TO* __restrict__ out, int ldo, int B, int L, int H, int hd, float eps,
                                                            float q_scale) {
     const int lane = threadIdx.x & 63;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -904,7 +904,7 @@ extern "C" int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const floa
     if (ldqkv % 8 || ldo % 8) return OD_ERR_ALIGN;
     const long M = (long)B * L;
     const int lph = hd / 8;
-    if (OD_QK_POS && (lph == 4 || lph == 8) && (H * lph) % 64 == 0 && ldqkv >= 2 * H * hd) {      // position-major kernel
+    if (OD_QK_POS && dtype != OD_F16 && (lph == 4 || lph == 8) && (H * lph) % 64 == 0 && ldqkv >= 2 * H * hd) {      // position-major kernel
         const int nit = 2 * H * lph / 64;
         if (nit == 2 || nit == 4 || nit == 8) {
             int bpw, lpw; qk_pos_split(B, L, bpw, lpw);
@@ -921,7 +921,10 @@ extern "C" int od_qk_norm_rope(int dtype, const void* qkv, int ldqkv, const floa
         }
     }
     dim3 grid((unsigned)((M + 3) / 4));
-    if (dtype == OD_BF16)
+    if (dtype == OD_F16)                       // bf16 in, IEEE half out ("attention in fp16")
+        OD_LAUNCH((qk_norm_rope_kernel<bf16_t, f16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,
+                  (f16_t*)qk_out, ldo, B, L, H, hd, eps, q_scale);
+    else if (dtype == OD_BF16)
         OD_LAUNCH((qk_norm_rope_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,
                   (bf16_t*)qk_out, ldo, B, L, H, hd, eps, q_scale);
     else

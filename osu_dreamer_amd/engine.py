@@ -84,6 +84,9 @@ class DenoiserEngine:
         # last backward used: its sticky error word is folded into every optimizer step on the device (attn_status_ptr)
         self._attn_ws_cache: Dict[tuple, "ops.FusedAttnBwdWorkspace"] = {}
         self._attn_ws = None
+        # "attention in fp16" (BASELINE configs[4]; Lightning precision 16-mixed in the reference's trainer, model.yml:12): q, k, v reach the
+        # attention core as IEEE half and its MFMAs are the f16 ones; everything around it stays bf16.  model.attn_dtype = torch.float16.
+        self.attn_f16 = False
 
     # ------------------------------------------------------------------ parameters
     def P(self, name: str) -> torch.Tensor:
@@ -153,7 +156,7 @@ class DenoiserEngine:
         dev = self.model.arena.data.device
         assert not (x3 and train), "the f32x3 product exists for the forward kernels only"
         x3 = bool(x3 and dtype == torch.float32)
-        key = (B, L, Ba, dtype, train, dev, x3)
+        key = (B, L, Ba, dtype, train, dev, x3, getattr(self.model, "attn_dtype", None))
         if key != self._plan_key:
             self.ws = Workspace(dev)
             self._plan_key = key
@@ -162,6 +165,9 @@ class DenoiserEngine:
             ops.rope_table(tab, L, self.hd)
         self.B, self.L, self.Ba, self.dtype, self.train, self.x3 = B, L, Ba, dtype, train, x3
         self.M, self.Ma = B * L, Ba * L
+        self.attn_f16 = getattr(self.model, "attn_dtype", None) == torch.float16
+        if self.attn_f16 and (dtype != torch.bfloat16 or self.hd != 64):
+            raise NotImplementedError("attn_dtype = float16 needs compute_dtype = bfloat16 and head_dim 64")
         return self.ws
 
     def buf(self, name, shape, dtype=None):
@@ -220,8 +226,9 @@ class DenoiserEngine:
             # --- attention branch (backbone.py:76-80, attn.py:74-84); h1 = norm + FiLM + proj_cl(a) came from the
             #     kernel that closed the previous layer
             qkv = self.lbuf("qkv", i, (M, 3 * dh))
-            if self.train or self.hd not in (32, 64) or (2 * dh) % 128:
-                qk = self.lbuf("qk", i, (M, 2 * dh))         # backward needs the pre-norm q, k as well
+            if self.train or self.attn_f16 or self.hd not in (32, 64) or (2 * dh) % 128:
+                # backward needs the pre-norm q, k as well.  attn_f16: qk and the v columns of qkv are written as IEEE half
+                qk = self.lbuf("qk16" if self.attn_f16 else "qk", i, (M, 2 * dh), torch.float16 if self.attn_f16 else None)
                 ops.gemm_nt_qkrope_split(h1, self.W(p + "attn.qkv_proj"), self.P(p + "attn.qkv_proj.bias"), qkv, qk,
                                          self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight"), tab, L, self.H,
                                          self.hd, FP32_EPS, x3=self.x3, q_scale=self.q_scale)
@@ -232,7 +239,7 @@ class DenoiserEngine:
                 qk = qkv
             y = self.lbuf("y", i, (M, dh))
             lse = self.lbuf("lse", i, (B, self.H, L), f32)
-            ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, lse, B, self.H, L, self.hd,
+            ops.flash_attn_fwd(qk[:, :dh], qk[:, dh:], self._v_of(qkv), y, lse, B, self.H, L, self.hd,
                                1.0 / math.sqrt(self.hd), x3=self.x3, q_prescaled=True)
             ao = self.lbuf("ao", i, (M, D))
             self.plain_gemm(y, self.W(p + "attn.out_proj"), self.P(p + "attn.out_proj.bias"), ao)
@@ -273,6 +280,11 @@ class DenoiserEngine:
         ops.uhead_fwd(xt, self._uhead_w(), fsum, self.U)
         ops.uhead_tail(fsum, self.ws.t["umod"], self.P("u_out.weight"), self.P("u_out.bias"), u, L, self.model.u_scale)
 
+    def _v_of(self, qkv: torch.Tensor) -> torch.Tensor:
+        """The v columns of a layer's qkv buffer as the attention core reads them (attn_f16: the same bytes hold IEEE half)."""
+        v = qkv[:, 2 * self.dh:]
+        return v.view(torch.float16) if self.attn_f16 else v
+
     def attn_bwd_passes(self) -> int:
         """L x L x hd MFMA passes the attention backward of this plan executes (5 = the algorithmic count: one fused kernel; 7 = the
         dK/dV + dQ kernel pair, which recomputes S and dP)."""
@@ -289,6 +301,8 @@ class DenoiserEngine:
         import os
         if self.dtype != torch.bfloat16 or self.hd != 64:
             return False
+        if self.attn_f16:
+            return True                     # the half-operand backward exists as the fused kernel only
         env = os.environ.get("OD_ATTN_BWD_FUSED", "")
         if env in ("0", "1"):
             return env == "1"
@@ -299,21 +313,21 @@ class DenoiserEngine:
         output, dqkv <- gradient of the qkv projection; norm weight gradients accumulate.  `core_only` (bench.py's roofline leg): just
         the attention backward as the step launches it, without the separate norm + RoPE backward pass that follows it."""
         t, dh, p = self.ws.t, self.dh, f"net.layers.{i}."
-        qk, qkv, y, lse = t[f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
+        qk, qkv, y, lse = t[f"qk16.{i}" if self.attn_f16 else f"qk.{i}"], t[f"qkv.{i}"], t[f"y.{i}"], t[f"lse.{i}"]
         wq, wk = self.P(p + "attn.q_norm.weight"), self.P(p + "attn.k_norm.weight")
         gq, gk = self.G(p + "attn.q_norm.weight"), self.G(p + "attn.k_norm.weight")
         scale = 1.0 / math.sqrt(self.hd)
         dqk = self.buf("d.qk", (self.M, 2 * dh))
         if self.fused_attn_bwd():
-            key = (self.B, self.H, self.L, qk.device)
+            key = (self.B, self.H, self.L, qk.device, qk.dtype)
             ws = self._attn_ws_cache.get(key)
             if ws is None:
                 if len(self._attn_ws_cache) >= 4:              # bounded: the oldest shape goes
                     self._attn_ws_cache.pop(next(iter(self._attn_ws_cache)))
-                ws = self._attn_ws_cache[key] = ops.FusedAttnBwdWorkspace(self.B, self.H, self.L, qk.device)
+                ws = self._attn_ws_cache[key] = ops.FusedAttnBwdWorkspace(self.B, self.H, self.L, qk.device, qk.dtype)
                 ws.checked = False
             self._attn_ws = ws
-            ops.flash_attn_bwd_fused(qk[:, :dh], qk[:, dh:], qkv[:, 2 * dh:], y, dy, lse, dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:],
+            ops.flash_attn_bwd_fused(qk[:, :dh], qk[:, dh:], self._v_of(qkv), y, dy, lse, dqk[:, :dh], dqk[:, dh:], dqkv[:, 2 * dh:],
                                      self.B, self.H, self.L, self.hd, scale, self._attn_ws, q_prescaled=True)
         else:
             if (self._attn_aux is None or self._attn_aux.device != qk.device) and qk.is_cuda:

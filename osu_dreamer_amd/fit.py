@@ -85,7 +85,10 @@ class Trainer:
 
     # ------------------------------------------------------------------
     def _autocast(self, device):
-        if self.precision.startswith("bf16"):
+        # "16-mixed" (Lightning: fp16 autocast + GradScaler): here bf16 compute with the attention core on IEEE-half operands
+        # (module.diffusion.attn_dtype = float16, set in _fit): accumulation is fp32 everywhere and dO is re-scaled by a power of two
+        # inside od_flash_attn_bwd_fused, so no loss scaling is needed
+        if self.precision.startswith("bf16") or self.precision.startswith("16"):
             return torch.autocast(device.type, dtype=torch.bfloat16)
         return torch.autocast(device.type, enabled=False)
 
@@ -166,6 +169,9 @@ class Trainer:
         reducer = None
         module.gradient_clip_val = self.gradient_clip_val
         module.to(device)
+        if self.precision.startswith("16"):
+            for m in (module.diffusion, module.diffusion_ema.module):
+                m.attn_dtype = torch.float16
         cfg = module.configure_optimizers()
         opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
         if ckpt_path:

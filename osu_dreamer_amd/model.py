@@ -168,6 +168,9 @@ class DiffusionModel(nn.Module):
         self.c0 = (1 - t99) ** 2 * d0_sq
         self.u_scale = math.sqrt(d0_sq)
         self.compute_dtype: Optional[torch.dtype] = None                 # None: follow autocast, else fp32
+        # torch.float16: "attention in fp16" — q, k, v reach the attention core as IEEE half and its MFMAs are the f16 ones, with bf16
+        # compute around it (BASELINE configs[4]; what Lightning's precision: 16-mixed, model.yml:12, asks of attn.py:82)
+        self.attn_dtype: Optional[torch.dtype] = None
         # fp32 no-grad forward / sampler: "f32" = exact fp32 MFMA chain (parity mode), "bf16x3" = three
         # bf16 MFMAs per product (~4e-6 per GEMM, 1.7x faster).  Training always uses "f32".
         self.f32_matmul = "f32"

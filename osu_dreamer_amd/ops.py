@@ -20,6 +20,8 @@ def dt_code(dtype: torch.dtype) -> int:
         return OD_F32
     if dtype == torch.bfloat16:
         return OD_BF16
+    if dtype == torch.float16:          # the operand type of the attention core when the host asks for "attention in fp16" (nothing else takes it)
+        return _lib.OD_F16
     raise TypeError(f"unsupported compute dtype {dtype}")
 
 
@@ -92,10 +94,14 @@ def gemm_nt_qkrope_split(A, W, bias, C, qk_out, wq, wk, table, L, H, hd, eps, x3
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and tuple(C.shape) == (M, N) and tuple(qk_out.shape) == (M, 2 * H * hd)
-    assert A.dtype == W.dtype == C.dtype == qk_out.dtype
+    assert A.dtype == W.dtype == C.dtype
+    # qk_out in torch.float16 = "attention in fp16": the roped q, k AND the v columns of C are then written as IEEE half
+    # (C stays a bf16 tensor whose last N - 2*H*hd columns hold half bit patterns: view them with .view(torch.float16))
+    assert qk_out.dtype == A.dtype or (qk_out.dtype == torch.float16 and A.dtype == torch.bfloat16)
     _f32(bias, wq, wk, table)
+    qk_code = _lib.OD_F16 if qk_out.dtype == torch.float16 else (OD_F32 if A.dtype == torch.float32 else code)
     _lib.lib().od_gemm_nt_qkrope_split(code, _p(A), _ld(A), _p(W), _ld(W), _p(bias), _p(C), _ld(C), _p(qk_out),
-                                       _ld(qk_out), M, N, K, _p(wq), _p(wk), _p(table), L, H, hd, eps, q_scale, _stream(A))
+                                       _ld(qk_out), qk_code, M, N, K, _p(wq), _p(wk), _p(table), L, H, hd, eps, q_scale, _stream(A))
 
 
 def gemm_tn(G, A, dW, n_cols=None, k_cols=None, dbias=None):
@@ -235,7 +241,9 @@ def qk_norm_rope_bwd(qkv, wq, wk, table, dqk, dqkv, dwq, dwk, B, L, H, hd, eps, 
 
 
 def flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale, x3=False, q_prescaled=False):
+    """q, k, v in torch.float16 (o stays bf16): the half-operand kernel ("attention in fp16")."""
     _f32(lse)
+    assert q.dtype == k.dtype == v.dtype and (o.dtype == q.dtype or (q.dtype == torch.float16 and o.dtype == torch.bfloat16))
     _lib.lib().od_flash_attn_fwd(mm_code(q.dtype, x3), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(lse),
                                  B, H, L, hd, scale, int(q_prescaled), _stream(q))
 
@@ -271,11 +279,13 @@ class FusedAttnBwdWorkspace:
     """Caller-owned device memory of od_flash_attn_bwd_fused for one (B, H, L): control block + chain flags (zeroed once here; every call
     leaves them zero), the start values (-lse', -delta) and the running dQ tiles.  One instance serves every layer of a step (same stream)."""
 
-    def __init__(self, B, H, L, device):
+    def __init__(self, B, H, L, device, dtype=torch.bfloat16):
+        """`dtype` torch.float16: room for the staged half copy of dO as well ("attention in fp16")."""
         import ctypes
         total, zero = ctypes.c_long(), ctypes.c_long()
-        _lib.lib().od_flash_attn_bwd_fused_ws_bytes(B, H, L, ctypes.byref(total), ctypes.byref(zero))
+        _lib.lib().od_flash_attn_bwd_fused_ws_bytes(dt_code(dtype), B, H, L, ctypes.byref(total), ctypes.byref(zero))
         self.shape = (B, H, L)
+        self.dtype = dtype
         self.bytes = total.value
         assert zero.value <= self.bytes
         self.zero_bytes = zero.value
@@ -299,9 +309,12 @@ class FusedAttnBwdWorkspace:
 
 
 def flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, scale, ws: FusedAttnBwdWorkspace, q_prescaled=False):
-    """The 5-pass fused attention backward (bf16, head_dim 64): dq, dk, dv from one kernel, dQ summed over key blocks by the L2 chain."""
+    """The 5-pass fused attention backward (bf16, head_dim 64): dq, dk, dv from one kernel, dQ summed over key blocks by the L2 chain.
+    q, k, v in torch.float16: the half-operand form (o, do, dq, dk, dv stay bf16; the workspace must have been made for float16)."""
     _f32(lse)
     assert ws.shape == (B, H, L), (ws.shape, (B, H, L))
+    assert q.dtype == k.dtype == v.dtype and o.dtype == do.dtype == dq.dtype == dk.dtype == dv.dtype == torch.bfloat16
+    assert q.dtype == torch.bfloat16 or (q.dtype == torch.float16 and ws.dtype == torch.float16)
     _lib.lib().od_flash_attn_bwd_fused(dt_code(q.dtype), _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(do), _ld(do),
                                        _p(lse), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), B, H, L, hd, scale, int(q_prescaled),
                                        _p(ws.buf), ws.bytes, _stream(q))

@@ -216,6 +216,7 @@ template <class T> inline T __shfl_down(T v, int d, int width = 64) { (void)widt
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
@@ -232,7 +233,7 @@ inline float bf16_to_f32(unsigned short h) { uint32_t u = (uint32_t)h << 16; flo
 
 // D = A(16x32) * B(32x16) + C.   lane l: A[row l&15][k 8*(l>>4)+j], B[k 8*(l>>4)+j][col l&15],
 // C/D[row 4*(l>>4)+r][col l&15]
-inline emu_f32x4 mfma_16x16x32_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c) {
+template <float (*DEC)(unsigned short)> inline emu_f32x4 mfma_16x16x32_b16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c) {
     State& s = S();
     int w = wave_id(), l = lane_id();
     unsigned char* mine = s.xbuf[w][l];
@@ -246,7 +247,7 @@ inline emu_f32x4 mfma_16x16x32_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c) {
         for (int g = 0; g < 4; g++) {
             const unsigned short* pa = (const unsigned short*)(s.xbuf[w][g * 16 + row]);
             const unsigned short* pb = (const unsigned short*)(s.xbuf[w][g * 16 + col] + 16);
-            for (int j = 0; j < 8; j++) acc = fmaf(bf16_to_f32(pa[j]), bf16_to_f32(pb[j]), acc);
+            for (int j = 0; j < 8; j++) acc = fmaf(DEC(pa[j]), DEC(pb[j]), acc);
         }
         d[r] = acc;
     }
@@ -278,7 +279,7 @@ inline emu_f32x4 mfma_16x16x4_f32(float a, float b, emu_f32x4 c) {
 }
 // D = A(32x16) * B(16x32) + C.  lane l: A[l&31][8*(l>>5)+j], B[8*(l>>5)+j][l&31],
 // C/D[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31]
-inline emu_f32x16 mfma_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c) {
+template <float (*DEC)(unsigned short)> inline emu_f32x16 mfma_32x32x16_b16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c) {
     State& s = S();
     int w = wave_id(), l = lane_id();
     unsigned char* mine = s.xbuf[w][l];
@@ -292,13 +293,20 @@ inline emu_f32x16 mfma_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c) {
         for (int g = 0; g < 2; g++) {
             const unsigned short* pa = (const unsigned short*)(s.xbuf[w][g * 32 + row]);
             const unsigned short* pb = (const unsigned short*)(s.xbuf[w][g * 32 + col] + 16);
-            for (int j = 0; j < 8; j++) acc = fmaf(bf16_to_f32(pa[j]), bf16_to_f32(pb[j]), acc);
+            for (int j = 0; j < 8; j++) acc = fmaf(DEC(pa[j]), DEC(pb[j]), acc);
         }
         d[r] = acc;
     }
     wave_barrier();
     return d;
 }
+// IEEE half <-> float through the host compiler's _Float16
+inline float f16_to_f32(unsigned short h) { _Float16 x; memcpy(&x, &h, 2); return (float)x; }
+inline unsigned short f32_to_f16(float f) { _Float16 x = (_Float16)f; unsigned short h; memcpy(&h, &x, 2); return h; }
+inline emu_f32x4 mfma_16x16x32_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c) { return mfma_16x16x32_b16<bf16_to_f32>(a, b, c); }
+inline emu_f32x4 mfma_16x16x32_f16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c) { return mfma_16x16x32_b16<f16_to_f32>(a, b, c); }
+inline emu_f32x16 mfma_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c) { return mfma_32x32x16_b16<bf16_to_f32>(a, b, c); }
+inline emu_f32x16 mfma_32x32x16_f16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c) { return mfma_32x32x16_b16<f16_to_f32>(a, b, c); }
 }  // namespace emu
 
 namespace emu {

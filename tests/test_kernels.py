@@ -588,6 +588,45 @@ def test_flash_attn_bwd_fused(dev, B, H, L, pre):
     assert rel_l2(dq.float(), dq7.float().cpu()) < 6e-3                                                     # fp32 chain vs in-register sum
 
 
+@pytest.mark.parametrize("pre", [False, True])
+@pytest.mark.parametrize("B,H,L", [(2, 2, 75), (1, 3, 200), (1, 9, 450), (2, 1, 385)])
+def test_flash_attn_f16_operands(dev, B, H, L, pre):
+    """"Attention in fp16" (BASELINE configs[4]): q, k, v as IEEE half, P / dS / the staged dO half inside the kernels (v_mfma_f32_*_f16),
+    o, dO, dq, dk, dv bf16 — od_flash_attn_fwd and od_flash_attn_bwd_fused with OD_F16 against dense fp32 autograd on the SAME (half-rounded)
+    inputs.  Half carries 3 more mantissa bits than bf16: P and dS are 8x finer, so the error is what the bf16 OUTPUT rounding leaves.
+    dO is tiny on purpose (1e-6: a mean-reduced loss) — it must survive through the power-of-two re-scaling, not vanish in half."""
+    hd = 64
+    g = torch.Generator().manual_seed(41)
+    M, dh = B * L, H * hd
+    scale = 1 / math.sqrt(hd)
+    c = scale * math.log2(math.e)
+    f16, bf = torch.float16, torch.bfloat16
+    q = (torch.randn(M, dh, generator=g) * (c if pre else 1.0)).to(f16).to(dev)
+    k = torch.randn(M, dh, generator=g).to(f16).to(dev)
+    v = (torch.randn(M, dh, generator=g) * 3.0).to(f16).to(dev)
+    o = torch.zeros(M, dh, dtype=bf, device=dev)
+    lse = torch.zeros(B, H, L, device=dev)
+    ops.flash_attn_fwd(q, k, v, o, lse, B, H, L, hd, scale, q_prescaled=pre)
+    do = (torch.randn(M, dh, generator=g) * 1e-6).to(bf).to(dev)
+
+    def heads(t):
+        return t.reshape(B, L, H, hd).permute(0, 2, 1, 3)
+    qr, kr, vr = (leaf(t) for t in (q, k, v))
+    s = heads(qr) @ heads(kr).transpose(-1, -2) * (math.log(2.0) if pre else scale)
+    ref = (torch.softmax(s, -1) @ heads(vr)).permute(0, 2, 1, 3).reshape(M, dh)
+    assert rel_l2(o.float(), ref) < 4e-3                       # bf16 output rounding (2^-9 per element)
+    ref.backward(do.float().cpu())
+    ws = ops.FusedAttnBwdWorkspace(B, H, L, dev, torch.float16)
+    for rep in range(2):
+        dq, dk, dv = (torch.full((M, dh), float("nan"), dtype=bf, device=dev) for _ in range(3))
+        ops.flash_attn_bwd_fused(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, scale, ws, q_prescaled=pre)
+        assert ws.status() == 0
+        # o is bf16 (delta = sum dO o carries its rounding) and the outputs are bf16: 5e-3; the bf16-operand kernel is held to 3e-2
+        assert rel_l2(dv.float(), vr.grad) < 5e-3
+        assert rel_l2(dk.float(), kr.grad) < 8e-3
+        assert rel_l2(dq.float(), qr.grad) < 8e-3
+
+
 def test_flash_attn_bwd_fused_refuses_another_shape(dev):
     """A workspace's running tiles carry write numbers that continue from launch to launch: a launch with another (B, H, L) must be refused
     (status 2, nothing computed) instead of waiting for numbers that never come."""

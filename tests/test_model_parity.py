@@ -227,7 +227,9 @@ def test_bf16x3_forward_when_the_qkv_epilogue_does_not_apply(dev):
 BF16_K, BF16_FLOOR = 3.0, 4e-3
 
 
-def run_bf16_training_case(name, dev):
+def run_bf16_training_case(name, dev, attn_dtype=None, target="f32"):
+    """`attn_dtype` torch.float16 + target "f16": the step with the attention core on half operands, held to the reference's OWN
+    fp16-autocast run (tests/golden/train_f16_*.npz, loss-scaled as Lightning's 16-mixed does) within the reference's bf16 noise."""
     fx = load(name)
     d = dims_of(fx)
     seed = int(fx["seed"])
@@ -235,36 +237,54 @@ def run_bf16_training_case(name, dev):
     data = O.synthetic_batch(d, int(fx["B"]), int(fx["L"]), seed=seed + 1)
     tr = make_trainer(d, P, dev)
     model = tr.diffusion
-    model.compute_dtype = torch.bfloat16
+    model.compute_dtype, model.attn_dtype = torch.bfloat16, attn_dtype
     dd = {k: v.to(dev) for k, v in data.items()}
     opt = tr.configure_optimizers()["optimizer"]
     opt.zero_grad()
     loss, logs = tr(model, dd["h"], dd["z"], dd["s"], None, t=fx["t_used"].to(dev), x0=dd["x0"])
     loss.backward()
+    if attn_dtype is not None:
+        assert model.engine.attn_f16 and model.engine.fused_attn_bwd() and model.engine.attn_bwd_passes() == 5
+        model.engine.check_attn_status()
+    T = target                                   # what the step is compared with; the bf16-vs-f32 distance of the reference is the yardstick
     ref32, ref16 = float(fx["f32.loss"]), float(fx["bf16.loss"])
-    assert abs(float(loss.detach()) - ref32) <= BF16_K * abs(ref16 - ref32) + 2e-3 * ref32, (float(loss.detach()), ref32, ref16)
+    refT = float(fx[T + ".loss"])
+    assert abs(float(loss.detach()) - refT) <= BF16_K * abs(ref16 - ref32) + 2e-3 * ref32, (float(loss.detach()), refT, ref32, ref16)
     gn = float(model.arena.grad.double().norm())
     gn32, gn16 = float(fx["f32.grad_norm"]), float(fx["bf16.grad_norm"])
-    assert abs(gn - gn32) <= BF16_K * abs(gn16 - gn32) + 5e-3 * gn32, (gn, gn32, gn16)
+    assert abs(gn - float(fx[T + ".grad_norm"])) <= BF16_K * abs(gn16 - gn32) + 5e-3 * gn32, (gn, gn32, gn16)
     ratios = []
     for k, p in model.named_parameters():
         g = p.grad.detach().cpu()
         if "f32.grad." + k in fx:
-            r32, r16 = fx["f32.grad." + k], fx["bf16.grad." + k]
+            r32, r16, rT = fx["f32.grad." + k], fx["bf16.grad." + k], fx[T + ".grad." + k]
             mine = g
         else:                                    # full-width fixture: strided sub-sample + norm
-            r32, r16 = fx["f32.gradsub." + k], fx["bf16.gradsub." + k]
+            r32, r16, rT = fx["f32.gradsub." + k], fx["bf16.gradsub." + k], fx[T + ".gradsub." + k]
             n = g.numel()
             mine = g.flatten()[::max(1, n // 64)][:64]
             n32 = float(fx["f32.gradnorm." + k])
-            assert abs(float(g.norm()) - n32) <= BF16_K * abs(float(fx["bf16.gradnorm." + k]) - n32) + 2e-2 * n32 + 1e-7, k
+            assert abs(float(g.norm()) - float(fx[T + ".gradnorm." + k])) <= BF16_K * abs(float(fx["bf16.gradnorm." + k]) - n32) + 2e-2 * n32 + 1e-7, k
         if float(r32.norm()) == 0:
             continue
-        e_ref, e_mine = rel_l2(r16, r32), rel_l2(mine, r32)
+        e_ref, e_mine = rel_l2(r16, r32), rel_l2(mine, rT)
         assert e_mine <= BF16_K * e_ref + BF16_FLOOR, (k, e_mine, e_ref)
         ratios.append(e_mine / max(e_ref, 1e-9))
-    print(f"[{name}] bf16 step: loss {float(loss.detach()):.5f} (ref fp32 {ref32:.5f}, ref bf16 {ref16:.5f}); "
-          f"median grad error = {float(np.median(ratios)):.2f} x the reference's own bf16 error, worst {max(ratios):.2f} x")
+    print(f"[{name}] bf16 step{' + f16 attention, against the reference fp16-autocast run' if attn_dtype is not None else ''}: "
+          f"loss {float(loss.detach()):.5f} (ref fp32 {ref32:.5f}, ref bf16 {ref16:.5f}, ref {T} {refT:.5f}); "
+          f"median grad distance = {float(np.median(ratios)):.2f} x the reference's own bf16 error, worst {max(ratios):.2f} x")
+
+
+def test_f16_attention_step_small(dev):
+    run_bf16_training_case("train_f16_small_hd64_b2_l230", dev, attn_dtype=torch.float16, target="f16")
+
+
+@pytest.mark.gpu
+def test_f16_attention_step_full_width():
+    from osu_dreamer_amd import _lib
+    _lib._lib = None
+    _lib.lib()
+    run_bf16_training_case("train_f16_full_d2_b2_l96", torch.device("cuda:0"), attn_dtype=torch.float16, target="f16")
 
 
 @pytest.mark.parametrize("name", ["train_bf16_tiny_b3_l40"])
@@ -304,6 +324,37 @@ def test_fused_attention_backward_in_the_step(dev, monkeypatch):
         grads[fused] = (float(loss.detach()), model.arena.grad.detach().cpu().clone())
     assert grads["0"][0] == grads["1"][0]
     assert rel_l2(grads["1"][1], grads["0"][1]) < 2e-3
+
+
+def test_f16_attention_in_the_step(dev):
+    """model.attn_dtype = float16 ("attention in fp16", BASELINE configs[4]): the bf16 training step with the attention core on half operands
+    against the same step on bf16 operands and against the fp32 oracle — the half form must be at least as close to fp32 as the bf16 form
+    (its P / dS / q / k / v carry 3 more mantissa bits), loss and every arena segment of the gradient."""
+    d = O.Dims(global_cond_dim=64, backbone_dim=128, n_heads=2, head_dim=64, depth=2, expand=2, radius=1, u_head_dim=16)
+    P = O.init_params(d, seed=11)
+    data = O.synthetic_batch(d, 2, 230, seed=12)
+    ref_loss, _, ref_grads = O.loss_and_grads(P, d, data["h"], data["z"], data["s"], data["t"], data["x0"])
+    out = {}
+    for name, adt in (("bf16", None), ("f16", torch.float16)):
+        tr = make_trainer(d, P, dev)
+        model = tr.diffusion
+        model.compute_dtype, model.attn_dtype = torch.bfloat16, adt
+        dd = {k: v.to(dev) for k, v in data.items()}
+        opt = tr.configure_optimizers()["optimizer"]
+        opt.zero_grad()
+        loss, _ = tr(model, dd["h"], dd["z"], dd["s"], None, t=dd["t"], x0=dd["x0"])
+        loss.backward()
+        assert model.engine.attn_f16 == (adt is not None)
+        if adt is not None:
+            assert model.engine.fused_attn_bwd() and model.engine.attn_bwd_passes() == 5
+            model.engine.check_attn_status()
+        errs = {k: rel_l2(p.grad, ref_grads[k]) for k, p in model.named_parameters() if float(ref_grads[k].norm()) > 0}
+        out[name] = (abs(float(loss.detach()) - float(ref_loss)) / abs(float(ref_loss)), errs)
+    worst = max(out["f16"][1][k] / max(out["bf16"][1][k], 1e-4) for k in out["f16"][1])
+    med = float(np.median([out["f16"][1][k] / max(out["bf16"][1][k], 1e-4) for k in out["f16"][1]]))
+    print(f"loss error vs fp32: bf16 {out['bf16'][0]:.2e}, f16-attention {out['f16'][0]:.2e}; gradient error ratio f16/bf16: median {med:.2f}, worst {worst:.2f}")
+    assert out["f16"][0] <= 1.5 * out["bf16"][0] + 1e-3
+    assert med <= 1.1 and worst <= 2.0
 
 
 def test_failed_attention_backward_is_caught_in_every_step(dev, monkeypatch):
