@@ -239,6 +239,24 @@ int od_sampler_step(float* x, const float* u, const float* v, const float* eta, 
 /* eta[0] = 1 - (sqrt(c0)/max(mean(u), sqrt(c0)+1e-6))^(1/num_steps); also eta[1] = mean(u).  replaces: model.py:131-132. */
 int od_sampler_eta(const float* u, float* eta, int B, float c0, int num_steps, void* stream);
 
+/* ---- deterministic accumulation (OD_DETERMINISTIC=1 in the Python host; not part of the reference's path) ------------------
+ * The step forms its weight / bias / modulation gradients and its loss scalars with fp32 atomics, whose order — and therefore last bits —
+ * changes from run to run.  With a table of registered destination ranges the same kernels add 2^40-scaled INTEGERS into a caller-owned
+ * 64-bit shadow of each destination instead (integer addition is associative: any order, same bits; |sum| < 2^23, resolution 2^-40), and
+ * od_det_flush folds a shadow range into its fp32 destination (dst += shadow * 2^-40; shadow = 0) before the destination's first reader.
+ * Values the format cannot hold (NaN, Inf, |v| >= 2^23) take the float atomic, so a non-finite gradient stays visible.
+ *   od_det_clear()                      forget every range and switch the mode off
+ *   od_det_register(base, count, sh)    add the range base[0..count) with its shadow sh (count x 8 bytes of device memory, ZERO); at most 14
+ *   od_det_enable(table_dev, stream)    copy the table into table_dev (od_det_table_bytes() bytes of device memory) and switch the mode on
+ *                                       for every later launch of this process; table_dev = NULL switches it off
+ *   od_det_flush(dst, count, stream)    dst[0..count) must lie inside one registered range
+ * Process-global state (one process drives one GPU). */
+int od_det_clear(void);
+int od_det_register(const float* base, long count, void* shadow_i64);
+int od_det_enable(void* table_dev, void* stream);
+int od_det_table_bytes(void);
+int od_det_flush(float* dst, long count, void* stream);
+
 /* ---- optimizer (models/diffusion/train.py:110-126; model.yml:39) --------------------- */
 /* out[0] += sum g^2.  `status` (may be NULL): device address of an error word of an earlier kernel of the step — the fused attention
  * backward's, workspace + od_flash_attn_bwd_fused_err_offset().  Non-zero there turns out[0] into NaN on the device: every step is checked

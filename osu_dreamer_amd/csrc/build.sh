@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libosudreamer_hip.so
-SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip attn_bwd_fused.hip style.hip latent.hip comm.hip calib.hip"
+SRCS="gemm.hip rowops.hip misc.hip heads.hip optim.hip attn.hip attn_bwd_fused.hip style.hip latent.hip comm.hip calib.hip det.hip"
 OBJS=""
 PIDS=""
 mkdir -p build

@@ -853,12 +853,14 @@ __device__ __forceinline__ void tn_frag(od_frag<float>&, const unsigned char*, i
 template <class T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ A, int lda,
                                                       float* __restrict__ dW, int lddw, float* __restrict__ dbias,
-                                                      int M, int N, int K, int m_per_block) {
+                                                      int M, int N, int K, int m_per_block, const OdDetTable* __restrict__ det) {
     constexpr bool TR = sizeof(T) == 2;
     constexpr int BR = 128 / (int)sizeof(T);  // reduction rows per slab (64 bf16 / 32 f32)
     constexpr int CH = 16 / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
     __shared__ float sred[128];
+    __shared__ long long sfix[128];        // the f32 path's bias sums: many threads per column -> fixed point (order-free)
+    __shared__ int s_bad;
     const int tiles_n = (N + BN - 1) / BN, tiles_k = (K + BM - 1) / BM;
     const int tile = blockIdx.x % (tiles_n * tiles_k), split = blockIdx.x / (tiles_n * tiles_k);
     const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BM;
@@ -868,7 +870,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const bool do_bias = dbias != nullptr && (tile % tiles_k) == 0;
-    if (tid < 128) sred[tid] = 0.f;
+    if (tid < 128) { sred[tid] = 0.f; sfix[tid] = 0; }
+    if (tid == 0) s_bad = 0;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -997,7 +1000,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
         if (do_bias) {
             const int cc = (tid % CPR) * CH;
 #pragma unroll
-            for (int e = 0; e < CH; e++) atomicAdd(&sred[cc + e], bsum[e]);
+            for (int e = 0; e < CH; e++) od_lds_fix_add(&sfix[cc + e], bsum[e], &s_bad);
+            __syncthreads();
+            if (tid < 128) sred[tid] = od_lds_unfix(sfix[tid], s_bad);
         }
     }
     const int col = lane & 15, g2 = lane >> 4;
@@ -1008,11 +1013,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wm * 64 + i * 16 + g2 * 4 + r, k = k0 + wn * 64 + j * 16 + col;
-                if (n < N && k < K) atomicAdd(dW + (size_t)n * lddw + k, acc[i][j][r]);
+                if (n < N && k < K) od_red_add(det, dW + (size_t)n * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
         __syncthreads();
-        if (tid < 128 && n0 + tid < N) atomicAdd(dbias + n0 + tid, sred[tid]);
+        if (tid < 128 && n0 + tid < N) od_red_add(det, dbias + n0 + tid, sred[tid]);       // (the bf16 path: two contributions per column — a + b = b + a)
     }
 }
 
@@ -1031,7 +1036,8 @@ __device__ __forceinline__ void tn512_frag(od_frag<bf16_t>& f, const unsigned ch
 }
 __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A, int lda,
                                                              float* __restrict__ dW, int lddw, float* __restrict__ dbias,
-                                                             int M, int N, int K, int m_per_block, int xcd_full) {
+                                                             int M, int N, int K, int m_per_block, int xcd_full,
+                                                             const OdDetTable* __restrict__ det) {
     const int xcd_order = xcd_full & 3;
     constexpr int STG = 65536;                 // G slab [64][256] 32 KiB + A slab [64][256] 32 KiB
     OD_DYN_SMEM(smem);
@@ -1140,11 +1146,196 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wm * 128 + i * 16 + g * 4 + r, k = k0 + wn * 64 + j * 16 + x;
-                if (n < N && k < K) atomicAdd(dW + (size_t)n * lddw + k, acc[i][j][r]);
+                if (n < N && k < K) od_red_add(det, dW + (size_t)n * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
         __syncthreads();
-        if (tid < 256 && n0 + tid < N) atomicAdd(dbias + n0 + tid, sred[tid]);
+        if (tid < 256 && n0 + tid < N) od_red_add(det, dbias + n0 + tid, sred[tid]);
+    }
+}
+
+// ---- TN, large variant, FOUR waves (round 5): gemm_nt_w4_kernel's organisation for the weight-gradient product.  One wave per SIMD, 128 (n) x 128 (k)
+// per wave with the 256 accumulators in AGPRs behind asm MFMAs, the fragments of the two 32-row halves of a 64-row slab in two register
+// sets, every transpose read / DMA piece alone between two MFMAs, two barriers per slab:
+//   MFMA   0.. 31   half 1's 32 transpose reads (one in front of every MFMA) -> register set 1;  [bias tiles: the slab's column sums]
+//   RELEASE barrier at 32 (the stage is in everybody's registers)
+//   MFMA  33.. 85   the wave's 16 DMA pieces of slab st + 2 into the released stage
+//   LANDED  barrier at 88: vmcnt(16) = everything but those 16 pieces, i.e. all of slab st + 1
+//   MFMA  88..119   half 0 of slab st + 1 from the other stage -> register set 0
+// against the 8-wave kernel's read-everything / 32-MFMAs / barrier per half (0.75 transpose reads per MFMA; here 0.5).  Same tile -> (n0, k0,
+// M-split) maps, same LDS image (512-byte rows, tn512_off), same fp32-atomic epilogue (od_red_add) and bias column sums as gemm_tn_big_kernel.
+#ifndef OD_TNW4_X
+#define OD_TNW4_X 0        // timing experiments only (wrong results): 2 no loop fragment reads, 16 no fetch
+#endif
+__global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A, int lda,
+                                                            float* __restrict__ dW, int lddw, float* __restrict__ dbias,
+                                                            int M, int N, int K, int m_per_block, int xcd_full,
+                                                            const OdDetTable* __restrict__ det) {
+    const int xcd_order = xcd_full & 3;
+    constexpr int STG = 65536;                 // G slab [64][256] 32 KiB + A slab [64][256] 32 KiB
+    OD_DYN_SMEM(smem);
+    float* sred = (float*)(smem + 2 * STG);    // 256 floats
+    const int tiles_n = (N + 255) / 256, tiles_k = (K + 255) / 256;
+    int tile, split;
+    if (xcd_order == 2) {
+        const int per_xcd = xcd_full >> 2;
+        const int gi = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= per_xcd) return;
+        split = gi / (tiles_n * tiles_k);
+        tile = gi % (tiles_n * tiles_k);
+    } else if (xcd_order) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        split = (slot / (tiles_n * tiles_k)) * 8 + xcd;
+        tile = slot % (tiles_n * tiles_k);
+    } else {
+        tile = blockIdx.x % (tiles_n * tiles_k); split = blockIdx.x / (tiles_n * tiles_k);
+    }
+    const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
+    const int mb = split * m_per_block;
+    int me = mb + m_per_block; me = me < M ? me : M;
+    if (mb >= M) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = od_uniform(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 15, g = lane >> 4;
+    const bool do_bias = dbias != nullptr && (tile % tiles_k) == 0;
+    sred[tid] = 0.f;
+
+    f32x4 acc[8][8];           // [n tile i][k tile j]
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4)(0.f);
+    const int nslab = (me - mb + 63) / 64;
+
+    // staging: waves 0, 1 stream the G slab (rows (wave & 1) * 32 ...), waves 2, 3 the A slab; 16 pieces of 2 rows x 512 B per wave and slab.
+    // Rows past this block's M range and bytes past the operand's end read as zero (the descriptor ends at row `me`, the last row's width
+    // rounded up to a 16-byte chunk: the hardware range-checks per dword).
+    const bool isa = wave >= 2;
+    const int ld = isa ? lda : ldg, c0 = isa ? k0 : n0, width = isa ? K : N;
+    const bf16_t* opnd = (isa ? A : G) + (size_t)mb * ld + c0;
+    const long avail = (long)(me - mb - 1) * ld + ((width - c0 + 7) & ~7);
+    od_srd_t srd = od_make_srd(opnd, (unsigned)((avail > 0 ? avail : 0) * 2));
+    if (OD_TNW4_X & 16) od_srd_set_bytes(srd, 0u);
+    unsigned voff8[8];                                                       // by piece & 7 (the swizzle key is row & 15 = (2 i + lane / 32) & 15)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int r = ((wave & 1) * 16 + i) * 2 + (lane >> 5);              // row of the 64-row slab (pieces 8..15: + 16 rows, same key)
+        const int pos = lane & 31;                                          // 16-byte position within the 512-byte LDS row
+        const int slot = ((((pos >> 1) ^ (r & 15)) << 1) | (pos & 1));
+        voff8[i] = (unsigned)(r * ld * 2 + slot * 16);
+    }
+    const unsigned lds_mine = od_lds_addr(smem) + (isa ? 32768u : 0u) + (unsigned)(wave & 1) * 16384u;
+    const unsigned half_stride = (unsigned)(16 * ld * 2);                    // pieces 8..15 sit 16 rows further down
+
+    od_frag<bf16_t> fa[2][8], fb[2][8];                    // [half = register set][tile]: fa from the G slab (n), fb from the A slab (k)
+    // read r of a half's 32: r = 2 t + e -> transpose read e of fragment t (t < 8: fa, else fb), in the order the MFMAs first use them
+    // (MFMA n of a half = (i = n >> 3, j = n & 7): fa[0] and all eight fb first)
+    auto rd_one = [&](const unsigned char* st, int u, int r) {
+        const int t = r >> 1, e = r & 1;
+        const int seq = t == 0 ? 0 : t < 9 ? t + 7 : t - 8;            // fragment order: fa[0], fb[0..7], fa[1..7]  -> index into (fa: 0..7, fb: 8..15)
+        const bool is_b = seq >= 8;
+        const int idx = seq & 7;
+        const unsigned char* base = is_b ? st + 32768 : st;
+        const int cc = (is_b ? wn : wm) * 128 + idx * 16;
+        const int cb = (cc + 4 * (x & 3)) * 2, rr = 32 * u + 4 * g + (x >> 2) + 16 * e;
+        const s16x4 v4 = od_lds_tr_read((const bf16_t*)(base + tn512_off(rr, cb)));
+        od_frag<bf16_t>& f = is_b ? fb[u][idx] : fa[u][idx];
+        f.v[4 * e] = v4[0]; f.v[4 * e + 1] = v4[1]; f.v[4 * e + 2] = v4[2]; f.v[4 * e + 3] = v4[3];
+    };
+    auto mma_one = [&](int u, int n) {
+        const int i = n >> 3, j = n & 7;
+#if defined(OD_EMU)
+        acc[i][j] = od_mma(fa[u][i], fb[u][j], acc[i][j]);
+#else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[u][i].v), "v"(fb[u][j].v));
+#endif
+    };
+    // bias tiles: column sums of the G slab, 16-byte row pieces (thread -> 8 columns x 8 rows per slab), before the stage is released
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) bs[e] = 0.f;
+    const int bcol8 = (tid & 31) * 8, brow0 = (tid >> 5) * 8;
+
+    // prologue: slabs 0 and 1 in flight, slab 0 landed, its half-0 fragments in register set 0
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const unsigned so = (unsigned)t * 64u * (unsigned)ld * 2u;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            od_buffer_lds16_at(srd, voff8[i & 7], so + (unsigned)(i >> 3) * half_stride, lds_mine + (unsigned)t * STG + (unsigned)i * 1024u);
+    }
+    OD_WAIT_VMCNT(16);
+    od_barrier_raw();
+#pragma unroll
+    for (int r = 0; r < 32; r++) rd_one(smem, 0, r);
+
+    auto slab = [&](int st, const int xs) {
+        const unsigned char* X = smem + xs * STG;
+        const unsigned char* Y = smem + (xs ^ 1) * STG;
+        const unsigned dst = lds_mine + (unsigned)xs * STG;
+        const unsigned so = (unsigned)(st + 2) * 64u * (unsigned)ld * 2u;      // past the last slab: beyond the descriptor, zeros
+#pragma clang loop unroll(full)
+        for (int n = 0; n < 128; n++) {
+            if (n == 32) {
+                if (do_bias) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; rr++) {
+                        float v8[8];
+                        od_ld8((const bf16_t*)(X + tn512_off(brow0 + rr, bcol8 * 2)), v8);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) bs[e] += v8[e];
+                    }
+                }
+                OD_WAIT_LGKMCNT(0);
+                od_barrier_raw();
+            }
+            if (n == 88) {
+                OD_WAIT_VMCNT(16);
+                od_barrier_raw();
+            }
+            const bool d = n >= 33 && n < 33 + 48 && (n - 33) % 3 == 0;         // 16 pieces at MFMAs 33, 36, ..., 78
+            const int q = (n - 33) / 3;
+            if (d) od_dma_set_dst(dst + (unsigned)q * 1024u);
+            if (!(OD_TNW4_X & 2)) {
+                if (n < 32) rd_one(X, 1, n);
+                if (n >= 88 && n < 120) rd_one(Y, 0, n - 88);
+            }
+            mma_one(n >> 6, n & 63);
+            if (d) od_buffer_lds16_m0(srd, voff8[q & 7], so + (unsigned)(q >> 3) * half_stride);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int st = 0; st < nslab; st += 2) {
+        slab(st, 0);
+        if (st + 1 < nslab) slab(st + 1, 1);
+        else break;
+    }
+#if !defined(OD_EMU)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the epilogue reads the accumulators
+#endif
+    OD_WAIT_VMCNT(0);
+    if (do_bias) {
+        // the 8 row groups of a column meet in a FIXED order (deterministic), one group per barrier
+        for (int rg = 0; rg < 8; rg++) {
+            __syncthreads();
+            if ((tid >> 5) == rg) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) sred[bcol8 + e] += bs[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + wm * 128 + i * 16 + g * 4 + r, k = k0 + wn * 128 + j * 16 + x;
+                if (n < N && k < K) od_red_add(det, dW + (size_t)n * lddw + k, acc[i][j][r]);
+            }
+    if (do_bias) {
+        __syncthreads();
+        if (n0 + tid < N) od_red_add(det, dbias + n0 + tid, sred[tid]);
     }
 }
 
@@ -1155,14 +1346,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
 // column sums (bias gradients): out[n] += sum_m G[m][n]
 template <class T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ G, int ldg, float* __restrict__ out, int M, int N,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, const OdDetTable* __restrict__ det) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int mb = blockIdx.y * rows_per_block;
     int me = mb + rows_per_block; me = me < M ? me : M;
     if (n >= N) return;
     float s = 0.f;
     for (int m = mb; m < me; m++) s += od_t<T>::ld(G + (size_t)m * ldg + n);
-    atomicAdd(out + n, s);
+    od_red_add(det, out + n, s);
 }
 
 template <class T>
@@ -1286,7 +1477,11 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
                 grid_tn = per_xcd * 8;
             } else
                 grid_tn = xcd_order ? ((sp + 7) / 8) * 8 * tiles2 : tiles2 * sp;
-            OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(grid_tn), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order);
+            static const int tn_w4 = od_env_int("OD_TN_W4", 1);                  // (0: the 8-wave kernel; A/B)
+            if (tn_w4)
+                OD_LAUNCH_DYN(gemm_tn_w4_kernel, dim3(grid_tn), dim3(256), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active());
+            else
+                OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(grid_tn), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active());
             OD_CHECK_LAUNCH();
             return 0;
         }
@@ -1301,7 +1496,7 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
     mpb = ((mpb + BR - 1) / BR) * BR;
     if (mpb < 4 * BR) mpb = 4 * BR;
     splits = (M + mpb - 1) / mpb;
-    OD_LAUNCH((gemm_tn_kernel<T>), dim3(tiles * splits), dim3(256), 0, st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb);
+    OD_LAUNCH((gemm_tn_kernel<T>), dim3(tiles * splits), dim3(256), 0, st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -1404,8 +1599,8 @@ extern "C" int od_colsum(int dtype, const void* G, int ldg, float* out, int M, i
     if (M <= 0 || N <= 0) return OD_ERR_ARG;
     int rpb = (M + 255) / 256; if (rpb < 64) rpb = 64;
     dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
-    if (dtype == OD_BF16) OD_LAUNCH((colsum_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)G, ldg, out, M, N, rpb);
-    else OD_LAUNCH((colsum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)G, ldg, out, M, N, rpb);
+    if (dtype == OD_BF16) OD_LAUNCH((colsum_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)G, ldg, out, M, N, rpb, od_det_active());
+    else OD_LAUNCH((colsum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)G, ldg, out, M, N, rpb, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }

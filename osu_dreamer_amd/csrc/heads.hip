@@ -69,7 +69,7 @@ __device__ __forceinline__ void uhead_load_w4(UHeadSmem& S, const UHeadW& P, int
 }
 
 __global__ __launch_bounds__(256) void uhead_fwd_kernel(const float* __restrict__ xt, UHeadW P, float* __restrict__ fsum,
-                                                        int E, int L, int U, int nwin, int wpb) {
+                                                        int E, int L, int U, int nwin, int wpb, const OdDetTable* __restrict__ det) {
     __shared__ UHeadSmem S;
     const int b = blockIdx.y, t = threadIdx.x;
     const int i = t & 31, grp = t >> 5, cpg = U / 8;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void uhead_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < MAXU / 8; q++) {
         const float s = red32(acc[q]);
-        if (q < cpg && i == 0) atomicAdd(fsum + (size_t)b * U + grp * cpg + q, s);
+        if (q < cpg && i == 0) od_red_add(det, fsum + (size_t)b * U + grp * cpg + q, s);
     }
 }
 
@@ -106,8 +106,10 @@ struct UHeadG {
     float *dw0, *db0, *dw1, *db1, *dw3, *db3, *dw4, *db4;
 };
 
+// (the LDS sums below are each owned by ONE lane — channel c belongs to lane 0 of group c / cpg — so their order is fixed; only the
+// block-to-global step depends on the order blocks arrive in)
 __global__ __launch_bounds__(256) void uhead_bwd_kernel(const float* __restrict__ xt, UHeadW P, const float* __restrict__ dfm,
-                                                        UHeadG G, int E, int L, int U, int nwin) {
+                                                        UHeadG G, int E, int L, int U, int nwin, const OdDetTable* __restrict__ det) {
     __shared__ UHeadSmem S;
     __shared__ float sdw3[MAXU][3], sdb3[MAXU], sdb4[MAXU], sdw1[MAXU][MAXE], sdb1[MAXU], sdw0[MAXE][3], sdb0[MAXE];
     const int b = blockIdx.y, t = threadIdx.x;
@@ -226,19 +228,19 @@ __global__ __launch_bounds__(256) void uhead_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int o = t + 256 * q;
-        if (o < U * U) atomicAdd(G.dw4 + o, adw4[q]);
+        if (o < U * U) od_red_add(det, G.dw4 + o, adw4[q]);
     }
     __syncthreads();
     for (int c = t; c < U; c += 256) {
-        atomicAdd(G.db4 + c, sdb4[c]);
-        atomicAdd(G.db3 + c, sdb3[c]);
-        atomicAdd(G.db1 + c, sdb1[c]);
-        for (int j = 0; j < 3; j++) atomicAdd(G.dw3 + c * 3 + j, sdw3[c][j]);
-        for (int e = 0; e < E; e++) atomicAdd(G.dw1 + c * E + e, sdw1[c][e]);
+        od_red_add(det, G.db4 + c, sdb4[c]);
+        od_red_add(det, G.db3 + c, sdb3[c]);
+        od_red_add(det, G.db1 + c, sdb1[c]);
+        for (int j = 0; j < 3; j++) od_red_add(det, G.dw3 + c * 3 + j, sdw3[c][j]);
+        for (int e = 0; e < E; e++) od_red_add(det, G.dw1 + c * E + e, sdw1[c][e]);
     }
     if (t < E) {
-        atomicAdd(G.db0 + t, sdb0[t]);
-        for (int j = 0; j < 3; j++) atomicAdd(G.dw0 + t * 3 + j, sdw0[t][j]);
+        od_red_add(det, G.db0 + t, sdb0[t]);
+        for (int j = 0; j < 3; j++) od_red_add(det, G.dw0 + t * 3 + j, sdw0[t][j]);
     }
 }
 
@@ -261,7 +263,7 @@ __global__ void uhead_tail_kernel(const float* __restrict__ fsum, const float* _
 __global__ void uhead_tail_bwd_kernel(const float* __restrict__ fsum, const float* __restrict__ mod, const float* __restrict__ w,
                                       const float* __restrict__ bo, const float* __restrict__ du, float* __restrict__ dfm,
                                       float* __restrict__ dmod, float* __restrict__ dw, float* __restrict__ dbo,
-                                      int B, int U, int L, float u_scale) {
+                                      int B, int U, int L, float u_scale, const OdDetTable* __restrict__ det) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
     for (int c = lane; c < U; c += 64) {
@@ -275,13 +277,13 @@ __global__ void uhead_tail_bwd_kernel(const float* __restrict__ fsum, const floa
         const float f = fsum[(size_t)b * U + c] / (float)L;
         const float sc = mod[(size_t)b * 2 * U + c], sh = mod[(size_t)b * 2 * U + U + c];
         const float fm = f * (1.f + sc) + sh;
-        atomicAdd(dw + c, dy * fm);
+        od_red_add(det, dw + c, dy * fm);
         const float dfmv = dy * w[c];
         dfm[(size_t)b * U + c] = dfmv * (1.f + sc);      // gradient wrt the mean-pooled feature f
         dmod[(size_t)b * 2 * U + c] = dfmv * f;
         dmod[(size_t)b * 2 * U + U + c] = dfmv;
     }
-    if (lane == 0) atomicAdd(dbo, dy);
+    if (lane == 0) od_red_add(det, dbo, dy);
 }
 
 // ------------------------------------------------------------ loss
@@ -295,7 +297,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 
 __global__ __launch_bounds__(256) void make_xt_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                       const float* __restrict__ t, float* __restrict__ xt,
-                                                      float* __restrict__ dsq, int EL, int L) {
+                                                      float* __restrict__ dsq, int EL, int L, const OdDetTable* __restrict__ det) {
     __shared__ float sh[4];
     const int b = blockIdx.y;
     const float w = t[b];
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void make_xt_kernel(const float* __restrict__ 
         acc += d * d;
     }
     acc = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) atomicAdd(dsq + b, acc / (float)L);
+    if (threadIdx.x == 0) od_red_add(det, dsq + b, acc / (float)L);
 }
 
 // sums[b][0] = S1 = fds(xt - u v, x1), [1] = S2 = fds(v, vt), [2] = dS1/du ; dv = dLoss/dv
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
                                                         const float* __restrict__ u, const float* __restrict__ v,
                                                         const float* __restrict__ dsq, float* __restrict__ dv,
                                                         float* __restrict__ sums, int B, int EL, int L, float c0,
-                                                        float osl_w, float del_w) {
+                                                        float osl_w, float del_w, const OdDetTable* __restrict__ det) {
     __shared__ float sh[4];
     const int b = blockIdx.y;
     const float ub = u[b], den = dsq[b] + c0, ut = sqrtf(den);
@@ -334,9 +336,9 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
     }
     s1 = block_sum_256(s1, sh); s2 = block_sum_256(s2, sh); s3 = block_sum_256(s3, sh);
     if (threadIdx.x == 0) {
-        atomicAdd(sums + b * 3 + 0, s1 / (float)L);
-        atomicAdd(sums + b * 3 + 1, s2 / (float)L);
-        atomicAdd(sums + b * 3 + 2, s3 * invL2);
+        od_red_add(det, sums + b * 3 + 0, s1 / (float)L);
+        od_red_add(det, sums + b * 3 + 1, s2 / (float)L);
+        od_red_add(det, sums + b * 3 + 2, s3 * invL2);
     }
 }
 
@@ -389,7 +391,7 @@ extern "C" int od_uhead_fwd(const float* xt, const float* w0, const float* b0, c
     // windows a block walks: up to UWPB for long sequences, fewer when that would leave CUs idle (sampler: L ~ 1e3)
     int wpb = (int)((long)nwin * B / 512);
     wpb = wpb < 1 ? 1 : (wpb > UWPB ? UWPB : wpb);
-    OD_LAUNCH(uhead_fwd_kernel, dim3((nwin + wpb - 1) / wpb, B), dim3(256), 0, (hipStream_t)stream, xt, P, fsum, E, L, U, nwin, wpb);
+    OD_LAUNCH(uhead_fwd_kernel, dim3((nwin + wpb - 1) / wpb, B), dim3(256), 0, (hipStream_t)stream, xt, P, fsum, E, L, U, nwin, wpb, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -402,7 +404,7 @@ extern "C" int od_uhead_bwd(const float* xt, const float* w0, const float* b0, c
     const int nwin = (L + UOWN - 1) / UOWN;
     UHeadW P{w0, b0, w1, b1, w3, b3, w4, b4};
     UHeadG G{dw0, db0, dw1, db1, dw3, db3, dw4, db4};
-    OD_LAUNCH(uhead_bwd_kernel, dim3((nwin + UWPB - 1) / UWPB, B), dim3(256), 0, (hipStream_t)stream, xt, P, dfm, G, E, L, U, nwin);
+    OD_LAUNCH(uhead_bwd_kernel, dim3((nwin + UWPB - 1) / UWPB, B), dim3(256), 0, (hipStream_t)stream, xt, P, dfm, G, E, L, U, nwin, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -418,7 +420,7 @@ extern "C" int od_uhead_tail_bwd(const float* fsum, const float* mod, const floa
                                  float* dfm, float* dmod, float* dw_out, float* db_out, int B, int U, int L, float u_scale,
                                  void* stream) {
     OD_LAUNCH(uhead_tail_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, fsum, mod, w_out, b_out, du, dfm, dmod, dw_out,
-              db_out, B, U, L, u_scale);
+              db_out, B, U, L, u_scale, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -426,7 +428,7 @@ extern "C" int od_uhead_tail_bwd(const float* fsum, const float* mod, const floa
 extern "C" int od_make_xt(const float* x0, const float* x1, const float* t, float* xt, float* dsq, int B, int E, int L, void* stream) {
     const int EL = E * L;
     int gx = (EL + 255) / 256; if (gx > 256) gx = 256;
-    OD_LAUNCH(make_xt_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x0, x1, t, xt, dsq, EL, L);
+    OD_LAUNCH(make_xt_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x0, x1, t, xt, dsq, EL, L, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -435,7 +437,7 @@ extern "C" int od_loss_grad(const float* xt, const float* x1, const float* u, co
                             float* sums, int B, int E, int L, float c0, float osl_w, float del_w, void* stream) {
     const int EL = E * L;
     int gx = (EL + 255) / 256; if (gx > 256) gx = 256;
-    OD_LAUNCH(loss_grad_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, xt, x1, u, v, dsq, dv, sums, B, EL, L, c0, osl_w, del_w);
+    OD_LAUNCH(loss_grad_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, xt, x1, u, v, dsq, dv, sums, B, EL, L, c0, osl_w, del_w, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }

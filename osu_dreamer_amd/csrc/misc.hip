@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ 
 // element (all blocks hit the same D*(E+1) addresses, so the atomic count per address is what costs).
 template <class T>
 __global__ __launch_bounds__(256) void proj_in_bwd_kernel(const float* __restrict__ xt, const T* __restrict__ dx, int ldx,
-                                                          float* __restrict__ dW, float* __restrict__ db, int B, int E, int L, int D) {
+                                                          float* __restrict__ dW, float* __restrict__ db, int B, int E, int L, int D,
+                                                          const OdDetTable* __restrict__ det) {
     __shared__ float red[64][73];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int M = B * L;
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(256) void proj_in_bwd_kernel(const float* __restric
         if (wave == 0 && c < D) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                atomicAdd(db + c + k, red[lane][k * 9 + 8]);
+                od_red_add(det, db + c + k, red[lane][k * 9 + 8]);
 #pragma unroll
                 for (int e = 0; e < 8; e++)
-                    if (e < E) atomicAdd(dW + (size_t)(c + k) * E + e, red[lane][k * 9 + e]);
+                    if (e < E) od_red_add(det, dW + (size_t)(c + k) * E + e, red[lane][k * 9 + e]);
             }
         }
         __syncthreads();
@@ -211,9 +212,12 @@ constexpr int DW_RUN_BWD = 64;
 template <class T, int KS>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w,
                                                          const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx,
-                                                         float* __restrict__ dw, float* __restrict__ db, int L, int C) {
+                                                         float* __restrict__ dw, float* __restrict__ db, int L, int C,
+                                                         const OdDetTable* __restrict__ det) {
     constexpr int R = KS / 2;
-    __shared__ float red[1024 * (KS + 1)];
+    // fixed point (od_lds_fix_add): the block's sums do not depend on the order its threads arrive in.  C <= 1024 at k <= 5, 512 above (launcher)
+    __shared__ long long red[(KS <= 5 ? 1024 : 512) * (KS + 1)];
+    __shared__ int s_bad;
     const int cg = C / 8;
     const int b = blockIdx.y;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -222,7 +226,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x
     const int l0 = (int)(run * DW_RUN_BWD);
     const bool active = l0 < L;
     const int c = cgi * 8;
-    for (int i = threadIdx.x; i < C * (KS + 1); i += 256) red[i] = 0.f;
+    for (int i = threadIdx.x; i < C * (KS + 1); i += 256) red[i] = 0;
+    if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
     float wv[8][KS], adw[8][KS], adb[8];
 #pragma unroll
@@ -310,17 +315,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const T* __restrict__ x
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            atomicAdd(&red[(c + k) * (KS + 1) + KS], adb[k]);
+            od_lds_fix_add(&red[(c + k) * (KS + 1) + KS], adb[k], &s_bad);
 #pragma unroll
-            for (int j = 0; j < KS; j++) atomicAdd(&red[(c + k) * (KS + 1) + j], adw[k][j]);
+            for (int j = 0; j < KS; j++) od_lds_fix_add(&red[(c + k) * (KS + 1) + j], adw[k][j], &s_bad);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C * (KS + 1); i += 256) {
         const int ch = i / (KS + 1), j = i % (KS + 1);
-        const float v = red[i];
+        const float v = od_lds_unfix(red[i], s_bad);
         if (v != 0.f) {
-            if (j == KS) atomicAdd(db + ch, v); else atomicAdd(dw + (size_t)ch * KS + j, v);
+            if (j == KS) od_red_add(det, db + ch, v); else od_red_add(det, dw + (size_t)ch * KS + j, v);
         }
     }
 }
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(256) void linear_small_dw_kernel(const float* __res
 // weight-gradient GEMMs' split-M sums (tests/test_ddp_rccl.py holds a DDP step to 1e-4 of a plain step for that reason).
 constexpr int LS_NR = 32;
 __global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __restrict__ W, const float* __restrict__ dpre,
-                                                              float* __restrict__ dx, int B, int N, int K) {
+                                                              float* __restrict__ dx, int B, int N, int K, const OdDetTable* __restrict__ det) {
     __shared__ __attribute__((aligned(16))) float ds[LS_NR][32];
     const int n0 = blockIdx.x * LS_NR, b0 = blockIdx.y * 32, k = blockIdx.z * 256 + threadIdx.x;
     for (int i = threadIdx.x; i < LS_NR * 32; i += 256) {
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __res
     }
 #pragma unroll
     for (int i = 0; i < 32; i++)
-        if (b0 + i < B) atomicAdd(dx + (size_t)(b0 + i) * K + k, acc[i]);
+        if (b0 + i < B) od_red_add(det, dx + (size_t)(b0 + i) * K + k, acc[i]);
 }
 
 __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
@@ -496,7 +501,7 @@ extern "C" int od_proj_in_bwd(int dtype, const float* xt, const void* dx, int ld
     const long M = (long)B * L;
     if (M > 0x7fffffffL) return OD_ERR_UNSUPPORTED;
     int blocks = (int)((M + 63) / 64); if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
-    DISPATCH_T(dtype, OD_LAUNCH((proj_in_bwd_kernel<T_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, xt, (const T_*)dx, ldx, dW, db, B, E, L, D));
+    DISPATCH_T(dtype, OD_LAUNCH((proj_in_bwd_kernel<T_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, xt, (const T_*)dx, ldx, dW, db, B, E, L, D, od_det_active()));
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -566,13 +571,13 @@ extern "C" int od_dwconv(int dtype, const void* x, int ldx, const float* w, cons
 extern "C" int od_dwconv_bwd(int dtype, const void* x, int ldx, const float* w, const void* dy, int lddy, void* dx, int lddx,
                              float* dw, float* db, int B, int L, int C, int ksize, void* stream) {
     if (C % 8 || ldx % 8 || lddy % 8 || lddx % 8) return OD_ERR_ALIGN;
-    if (C > 1024) return OD_ERR_UNSUPPORTED;
+    if (C > 1024 || (ksize > 5 && C > 512)) return OD_ERR_UNSUPPORTED;
     const long threads = (long)(C / 8) * ((L + DW_RUN_BWD - 1) / DW_RUN_BWD);
     dim3 grid((unsigned)((threads + 255) / 256), B);
-    if (ksize == 5) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 5>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
-    else if (ksize == 3) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 3>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
-    else if (ksize == 7 && C <= 512) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 7>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
-    else if (ksize == 9 && C <= 512) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 9>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C));
+    if (ksize == 5) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 5>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C, od_det_active()));
+    else if (ksize == 3) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 3>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C, od_det_active()));
+    else if (ksize == 7 && C <= 512) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 7>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C, od_det_active()));
+    else if (ksize == 9 && C <= 512) DISPATCH_T(dtype, OD_LAUNCH((dwconv_bwd_kernel<T_, 9>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, w, (const T_*)dy, lddy, (T_*)dx, lddx, dw, db, L, C, od_det_active()));
     else return OD_ERR_UNSUPPORTED;
     OD_CHECK_LAUNCH();
     return 0;
@@ -596,7 +601,7 @@ extern "C" int od_linear_small_bwd(const float* x, const float* W, const float* 
         if (!accumulate_dx)
             OD_LAUNCH(zero_f32_kernel, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx, (long)B * K);
         OD_LAUNCH(linear_small_dx_kernel, dim3((N + LS_NR - 1) / LS_NR, (B + 31) / 32, (K + 255) / 256), dim3(256), 0, (hipStream_t)stream, W,
-                  (const float*)dpre, dx, B, N, K);
+                  (const float*)dpre, dx, B, N, K, od_det_active());
     }
     OD_CHECK_LAUNCH();
     return 0;

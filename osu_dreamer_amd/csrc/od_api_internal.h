@@ -25,3 +25,8 @@ inline int od_num_cus() {
     return cache[dev];
 }
 #endif
+
+// The active table of od_det_* (device memory; NULL = plain float atomics): every launcher of a kernel that accumulates with atomics
+// hands it to the kernel.  One process drives one GPU: process-global.
+struct OdDetTable;
+const OdDetTable* od_det_active();

@@ -72,7 +72,16 @@ __device__ __forceinline__ f16_t od_f2h(float f) { return f16_t{emu::f32_to_f16(
 __device__ __forceinline__ float od_h2f(f16_t h) { return (float)__builtin_bit_cast(_Float16, h.bits); }
 __device__ __forceinline__ f16_t od_f2h(float f) { return f16_t{__builtin_bit_cast(unsigned short, (_Float16)f)}; }
 #endif
+#if defined(OD_EMU)
 __device__ __forceinline__ uint32_t od_pack_h2(float lo, float hi) { return (uint32_t)od_f2h(lo).bits | ((uint32_t)od_f2h(hi).bits << 16); }
+#else
+// one packed conversion (round to nearest even) where the target has it
+typedef _Float16 od_h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t od_pack_h2(float lo, float hi) {
+    float __attribute__((ext_vector_type(2))) v; v[0] = lo; v[1] = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, od_h2_t));
+}
+#endif
 // two floats -> one dword of the 16-bit operand type T
 template <class T> __device__ __forceinline__ uint32_t od_pack2(float lo, float hi);
 template <> __device__ __forceinline__ uint32_t od_pack2<bf16_t>(float lo, float hi) { return od_pack_bf2(lo, hi); }
@@ -165,7 +174,11 @@ template <> __device__ __forceinline__ void od_st8_nt<bf16_t>(bf16_t* p, const f
     for (int i = 0; i < 4; i++) r[i] = od_pack_bf2(v[2 * i], v[2 * i + 1]);
     // inline asm, not __builtin_nontemporal_store: when a runtime flag selects between this and the plain store, hipcc merges the two
     // arms into ONE plain store and the hint is lost (seen in the ISA of gemm_nt_big_kernel: no `nt` on any store)
-    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(r) : "memory");
+    // The s_nop is the wait state the ISA asks for between a store of more than 64 bits and a VALU write of its data registers (the store
+    // reads them a cycle after issue).  hipcc's hazard pass inserts it for stores it can see; an asm statement is opaque to it, and two of
+    // these stores back to back — the second one's packing reusing the first one's registers — stored garbage (profiles/r05d: the
+    // "qk stored non-temporally" experiment wrote NaNs).
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(p), "v"(r) : "memory");
 }
 #endif
 
@@ -439,6 +452,39 @@ __device__ __forceinline__ void od_barrier_raw() { __syncthreads(); }
 #define OD_WAIT_LGKMCNT(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
 __device__ __forceinline__ void od_barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
 #endif
+
+// ---------------------------------------------------------------------------------
+// Deterministic accumulation (OD_DETERMINISTIC; od_det_* in det.hip).  Every sum the step forms with fp32 atomics — weight-gradient
+// split-K partials, per-(batch, channel) modulation gradients, bias / norm-weight gradients, the loss and norm scalars — depends on the order the
+// blocks arrive in, so two runs of one step differ in the last bits (5.9e-5 rel-L2 at the bench shape).  With a table of registered destination
+// ranges the same kernels add 2^40-scaled INTEGERS into a 64-bit shadow of the destination instead: integer addition is associative, the
+// result is the same whatever the order (and wrap-around in between is harmless: only the final sum has to fit, |sum| < 2^23), and
+// od_det_flush folds the shadow into the fp32 destination before its first reader.  Values the shadow cannot hold (NaN, Inf, |v| >= 2^23)
+// take the float atomic, so a non-finite gradient stays visible.  det == NULL: the plain float atomic.
+struct OdDetRange { const float* base; long long count; long long* shadow; };
+struct OdDetTable { int n; int pad; OdDetRange r[14]; };
+__device__ __forceinline__ long long od_fix(float v) { return (long long)((double)v * 1099511627776.0); }       // 2^40; exact product, truncated
+__device__ __forceinline__ float od_unfix(long long s) { return (float)((double)s * (1.0 / 1099511627776.0)); }
+__device__ __forceinline__ void od_red_add(const OdDetTable* det, float* p, float v) {
+    if (det && fabsf(v) < 8388608.f) {
+        const int n = det->n;
+        for (int i = 0; i < n; i++) {
+            const long long off = p - det->r[i].base;
+            if (off >= 0 && off < det->r[i].count) {
+                atomicAdd((unsigned long long*)(det->r[i].shadow + off), (unsigned long long)od_fix(v));
+                return;
+            }
+        }
+    }
+    atomicAdd(p, v);
+}
+// Block-level sums in LDS: always fixed point (ds_add_u64), so the order the waves of a block arrive in never shows either.  A value the
+// format cannot hold sets the block's `bad` word instead; od_lds_unfix then hands back NaN for every slot of that block.
+__device__ __forceinline__ void od_lds_fix_add(long long* p, float v, int* bad) {
+    if (fabsf(v) < 8388608.f) atomicAdd((unsigned long long*)p, (unsigned long long)od_fix(v));
+    else *bad = 1;
+}
+__device__ __forceinline__ float od_lds_unfix(long long s, int bad) { return bad ? __builtin_nanf("") : od_unfix(s); }
 
 #define OD_CHECK_LAUNCH()                                \
     do {                                                 \

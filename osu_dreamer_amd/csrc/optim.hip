@@ -9,11 +9,17 @@
 namespace {
 
 // `status` (optional): a device-side error word of an earlier kernel of the step (the fused attention backward's, attn_bwd_fused.hip).  Non-zero
-// poisons the norm: NaN + anything = NaN whatever the order of the blocks' atomics — no host round trip, checked in EVERY step.
+// poisons the norm with NaN — no host round trip, checked in EVERY step.
+// The sum itself is order-free (always: the clip coefficient multiplies every gradient, so a norm that differs in its last bit from run to run
+// would make the whole step differ): every block leaves its partial in a slot, the LAST block to finish adds the slots up in index order.
+// (Process-global scratch: one process drives one GPU, and the optimizer's norm is one launch at a time.)
+constexpr int SQ_MAX_BLOCKS = 2048;
+__device__ float g_sq_part[SQ_MAX_BLOCKS];
+__device__ unsigned g_sq_done;
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ out,
                                                      const int* __restrict__ status) {
-    __shared__ float sh[4];
-    if (status && blockIdx.x == 0 && threadIdx.x == 0 && status[0] != 0) atomicAdd(out, __builtin_nanf(""));
+    __shared__ float sh[256];
+    __shared__ int s_last;
     float s = 0.f;
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -25,7 +31,32 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     s = od_wave_sum(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) {
+        g_sq_part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+#if !defined(OD_EMU)
+        __threadfence();
+#endif
+        s_last = atomicAdd(&g_sq_done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+#if !defined(OD_EMU)
+    __threadfence();
+#endif
+    float t = 0.f;                                        // fixed order: thread t sums slots t, t + 256, ...; then a fixed tree
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += ((volatile float*)g_sq_part)[i];
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float tot = sh[0];
+        if (status && status[0] != 0) tot = __builtin_nanf("");
+        out[0] += tot;
+        g_sq_done = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -72,7 +103,7 @@ extern "C" int od_ema_update(float* ema, const float* p, long n, float ema_decay
 }
 
 extern "C" int od_sqnorm(const float* g, long n, float* out, const int* status, void* stream) {
-    int blocks = (int)((n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    int blocks = (int)((n / 4 + 255) / 256); if (blocks > SQ_MAX_BLOCKS) blocks = SQ_MAX_BLOCKS; if (blocks < 1) blocks = 1;
     OD_LAUNCH(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out, status);
     OD_CHECK_LAUNCH();
     return 0;

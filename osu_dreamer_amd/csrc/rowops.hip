@@ -77,7 +77,7 @@ template <class T, int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_film_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ inv_rms,
                                                                const float* __restrict__ ssg, const T* __restrict__ dh, int lddh,
                                                                T* __restrict__ dres, int lddres, float* __restrict__ dssg,
-                                                               int B, int L, int C) {
+                                                               int B, int L, int C, const OdDetTable* __restrict__ det) {
     __shared__ float red[2][NCH * 512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void rmsnorm_film_bwd_kernel(const T* __restri
         __syncthreads();
     }
     for (int c = threadIdx.x; c < C; c += 256) {
-        atomicAdd(dssg + (size_t)b * 3 * C + c, red[0][c]);
-        atomicAdd(dssg + (size_t)b * 3 * C + C + c, red[1][c]);
+        od_red_add(det, dssg + (size_t)b * 3 * C + c, red[0][c]);
+        od_red_add(det, dssg + (size_t)b * 3 * C + C + c, red[1][c]);
     }
 }
 
@@ -230,7 +230,7 @@ template <class T, int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_gate_res_bwd_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ inv_rms,
                                                                    const float* __restrict__ ssg, const T* __restrict__ dy, int lddy,
                                                                    T* __restrict__ dh, int lddh, float* __restrict__ dssg,
-                                                                   int B, int L, int C) {
+                                                                   int B, int L, int C, const OdDetTable* __restrict__ det) {
     __shared__ float red[NCH * 512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_res_bwd_kernel(const T* __re
         }
         __syncthreads();
     }
-    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dssg + (size_t)b * 3 * C + 2 * C + c, red[c]);
+    for (int c = threadIdx.x; c < C; c += 256) od_red_add(det, dssg + (size_t)b * 3 * C + 2 * C + c, red[c]);
 }
 
 // ------------------------------------------------------------------ SwiGLU gate + RMS norm over Hf
@@ -390,7 +390,8 @@ template <class T, int NCH>
 __global__ __launch_bounds__(256) void final_proj_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ inv_rms,
                                                              const float* __restrict__ W, const float* __restrict__ dv,
                                                              T* __restrict__ dx, int lddx, float* __restrict__ dW,
-                                                             float* __restrict__ db, int B, int L, int C, int E) {
+                                                             float* __restrict__ db, int B, int L, int C, int E,
+                                                             const OdDetTable* __restrict__ det) {
     constexpr int MAXE = 8;
     __shared__ float red[MAXE * NCH * 512];
     __shared__ float redb[4][MAXE];
@@ -459,8 +460,8 @@ __global__ __launch_bounds__(256) void final_proj_bwd_kernel(const T* __restrict
         __syncthreads();
     }
     for (int e = 0; e < E; e++)
-        for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dW + (size_t)e * C + c, red[e * NCH * 512 + c]);
-    if (threadIdx.x < E) atomicAdd(db + threadIdx.x, redb[0][threadIdx.x] + redb[1][threadIdx.x] + redb[2][threadIdx.x] + redb[3][threadIdx.x]);
+        for (int c = threadIdx.x; c < C; c += 256) od_red_add(det, dW + (size_t)e * C + c, red[e * NCH * 512 + c]);
+    if (threadIdx.x < E) od_red_add(det, db + threadIdx.x, redb[0][threadIdx.x] + redb[1][threadIdx.x] + redb[2][threadIdx.x] + redb[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ q/k RMSNorm(hd) + RoPE
@@ -518,10 +519,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const T* __restri
                                                                const float* __restrict__ wk, const float* __restrict__ table,
                                                                const T* __restrict__ dqk, int lddqk, T* __restrict__ dqkv, int lddqkv,
                                                                float* __restrict__ dwq, float* __restrict__ dwk,
-                                                               int B, int L, int H, int hd, float eps, float q_scale) {
-    __shared__ float sdw[2][256];
+                                                               int B, int L, int H, int hd, float eps, float q_scale,
+                                                               const OdDetTable* __restrict__ det) {
+    __shared__ long long sdw[2][256];          // fixed point: the block's sum does not depend on the order its lanes arrive in
+    __shared__ int s_bad;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 512; i += 256) sdw[i >> 8][i & 255] = 0.f;
+    for (int i = threadIdx.x; i < 512; i += 256) sdw[i >> 8][i & 255] = 0;
+    if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
     const int lph = hd / 8, half = lph / 2;
     const int nchunks = 2 * H * lph;
@@ -588,13 +592,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const T* __restri
     const int c8 = lane % lph;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        atomicAdd(&sdw[0][c8 * 8 + e], aq[e]);
-        atomicAdd(&sdw[1][c8 * 8 + e], ak[e]);
+        od_lds_fix_add(&sdw[0][c8 * 8 + e], aq[e], &s_bad);
+        od_lds_fix_add(&sdw[1][c8 * 8 + e], ak[e], &s_bad);
     }
     __syncthreads();
     if (threadIdx.x < hd) {
-        atomicAdd(dwq + threadIdx.x, sdw[0][threadIdx.x]);
-        atomicAdd(dwk + threadIdx.x, sdw[1][threadIdx.x]);
+        od_red_add(det, dwq + threadIdx.x, od_lds_unfix(sdw[0][threadIdx.x], s_bad));
+        od_red_add(det, dwk + threadIdx.x, od_lds_unfix(sdw[1][threadIdx.x], s_bad));
     }
 }
 
@@ -662,10 +666,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_pos_bwd_kernel(const T* __re
                                                                    const float* __restrict__ wk, const float* __restrict__ table,
                                                                    const T* __restrict__ dqk, int lddqk, T* __restrict__ dqkv, int lddqkv,
                                                                    float* __restrict__ dwq, float* __restrict__ dwk,
-                                                                   int B, int L, float eps, float q_scale, int bpw, int lpw) {
+                                                                   int B, int L, float eps, float q_scale, int bpw, int lpw,
+                                                                   const OdDetTable* __restrict__ det) {
     constexpr int HD = 8 * LPH, HALFL = LPH / 2;
-    __shared__ float s_dw[2][HD];
-    for (int i = threadIdx.x; i < 2 * HD; i += 256) s_dw[i / HD][i % HD] = 0.f;
+    __shared__ long long s_dw[2][HD];          // fixed point (see qk_norm_rope_bwd_kernel)
+    __shared__ int s_bad;
+    for (int i = threadIdx.x; i < 2 * HD; i += 256) s_dw[i / HD][i % HD] = 0;
+    if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, c8 = lane % LPH;
     const int wpl = (B + bpw - 1) / bpw;
@@ -729,10 +736,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_pos_bwd_kernel(const T* __re
         for (int e = 0; e < 8; e++) { acc[0][e] += __shfl_xor(acc[0][e], msk); acc[1][e] += __shfl_xor(acc[1][e], msk); }
     if (lane < LPH) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) { atomicAdd(&s_dw[0][c8 * 8 + e], acc[0][e]); atomicAdd(&s_dw[1][c8 * 8 + e], acc[1][e]); }
+        for (int e = 0; e < 8; e++) { od_lds_fix_add(&s_dw[0][c8 * 8 + e], acc[0][e], &s_bad); od_lds_fix_add(&s_dw[1][c8 * 8 + e], acc[1][e], &s_bad); }
     }
     __syncthreads();
-    if (threadIdx.x < HD) { atomicAdd(dwq + threadIdx.x, s_dw[0][threadIdx.x]); atomicAdd(dwk + threadIdx.x, s_dw[1][threadIdx.x]); }
+    if (threadIdx.x < HD) {
+        od_red_add(det, dwq + threadIdx.x, od_lds_unfix(s_dw[0][threadIdx.x], s_bad));
+        od_red_add(det, dwk + threadIdx.x, od_lds_unfix(s_dw[1][threadIdx.x], s_bad));
+    }
 }
 
 __global__ void rope_table_kernel(float* __restrict__ table, int L, int hd) {
@@ -798,7 +808,7 @@ extern "C" int od_rmsnorm_film_bwd(int dtype, const void* x, int ldx, const floa
     dim3 grid((L + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD), B);
     DISPATCH_T_NCH(dtype, nch_for(C),
         OD_LAUNCH((rmsnorm_film_bwd_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, inv_rms, ssg,
-                  (const T_*)dh, lddh, (T_*)dres, lddres, dssg, B, L, C));
+                  (const T_*)dh, lddh, (T_*)dres, lddres, dssg, B, L, C, od_det_active()));
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -835,7 +845,7 @@ extern "C" int od_rmsnorm_gate_residual_bwd(int dtype, const void* h, int ldh, c
     dim3 grid((L + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD), B);
     DISPATCH_T_NCH(dtype, nch_for(C),
         OD_LAUNCH((rmsnorm_gate_res_bwd_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)h, ldh, inv_rms, ssg,
-                  (const T_*)dy, lddy, (T_*)dh, lddh, dssg, B, L, C));
+                  (const T_*)dy, lddy, (T_*)dh, lddh, dssg, B, L, C, od_det_active()));
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -882,10 +892,10 @@ extern "C" int od_final_norm_proj_out_bwd(int dtype, const void* x, int ldx, con
     dim3 grid((L + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD), B);
     if (dtype == OD_BF16)
         OD_LAUNCH((final_proj_bwd_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, inv_rms, W, dv,
-                  (bf16_t*)dx, lddx, dW, db, B, L, C, E);
+                  (bf16_t*)dx, lddx, dW, db, B, L, C, E, od_det_active());
     else
         OD_LAUNCH((final_proj_bwd_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, inv_rms, W, dv,
-                  (float*)dx, lddx, dW, db, B, L, C, E);
+                  (float*)dx, lddx, dW, db, B, L, C, E, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -948,7 +958,7 @@ extern "C" int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const 
             lpw *= 4;                                              // 4x fewer blocks meeting in the 2*hd global atomics
             const long waves = (long)((L + lpw - 1) / lpw) * ((B + bpw - 1) / bpw);
             dim3 g2((unsigned)((waves + 3) / 4));
-#define QKPB(TT, LPHV, NITV) OD_LAUNCH((qk_norm_rope_pos_bwd_kernel<TT, LPHV, NITV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (const TT*)dqk, lddqk, (TT*)dqkv, lddqkv, dwq, dwk, B, L, eps, q_scale, bpw, lpw)
+#define QKPB(TT, LPHV, NITV) OD_LAUNCH((qk_norm_rope_pos_bwd_kernel<TT, LPHV, NITV>), g2, dim3(256), 0, (hipStream_t)stream, (const TT*)qkv, ldqkv, wq, wk, table, (const TT*)dqk, lddqk, (TT*)dqkv, lddqkv, dwq, dwk, B, L, eps, q_scale, bpw, lpw, od_det_active())
 #define QKPB_T(TT) do { if (lph == 8) { if (nit == 2) QKPB(TT, 8, 2); else if (nit == 4) QKPB(TT, 8, 4); else QKPB(TT, 8, 8); } \
                         else { if (nit == 2) QKPB(TT, 4, 2); else if (nit == 4) QKPB(TT, 4, 4); else QKPB(TT, 4, 8); } } while (0)
             if (dtype == OD_BF16) QKPB_T(bf16_t); else QKPB_T(float);
@@ -961,10 +971,10 @@ extern "C" int od_qk_norm_rope_bwd(int dtype, const void* qkv, int ldqkv, const 
     dim3 grid((unsigned)((M + 4 * ROWS_PER_WAVE_BWD - 1) / (4 * ROWS_PER_WAVE_BWD)));
     if (dtype == OD_BF16)
         OD_LAUNCH((qk_norm_rope_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, wq, wk, table,
-                  (const bf16_t*)dqk, lddqk, (bf16_t*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps, q_scale);
+                  (const bf16_t*)dqk, lddqk, (bf16_t*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps, q_scale, od_det_active());
     else
         OD_LAUNCH((qk_norm_rope_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, ldqkv, wq, wk, table,
-                  (const float*)dqk, lddqk, (float*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps, q_scale);
+                  (const float*)dqk, lddqk, (float*)dqkv, lddqkv, dwq, dwk, B, L, H, hd, eps, q_scale, od_det_active());
     OD_CHECK_LAUNCH();
     return 0;
 }

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import ops
+from . import det, ops
 from ._lib import OD_ACT_NONE, OD_ACT_SILU
 
 FP32_EPS = float(torch.finfo(torch.float32).eps)   # nn.RMSNorm(eps=None), common/attn.py:71-72
@@ -46,6 +46,10 @@ class Workspace:
             t = torch.zeros(shape, dtype=dtype, device=self.device)
             self.t[name] = t
             self.bytes += t.numel() * t.element_size()
+            if name in det.WS_NAMES:              # OD_DETERMINISTIC: a buffer kernels accumulate into with atomics gets its integer shadow
+                ctx = det.context(self.device)
+                if ctx is not None:
+                    ctx.register(t)
         return t
 
 
@@ -87,6 +91,20 @@ class DenoiserEngine:
         # "attention in fp16" (BASELINE configs[4]; Lightning precision 16-mixed in the reference's trainer, model.yml:12): q, k, v reach the
         # attention core as IEEE half and its MFMAs are the f16 ones; everything around it stays bf16.  model.attn_dtype = torch.float16.
         self.attn_f16 = False
+
+    # ------------------------------------------------------------------ OD_DETERMINISTIC (det.py)
+    def _det_flush(self, *tensors):
+        """Fold the integer shadows of these accumulation targets into them (no-op unless the mode is on): before their first reader."""
+        ctx = det.context(self.model.arena.data.device)
+        if ctx is not None:
+            for t in tensors:
+                ctx.flush(t)
+
+    def _det_flush_segment(self, name: str):
+        ctx = det.context(self.model.arena.data.device)
+        if ctx is not None:
+            s, e = self.model.arena.segments(self.depth)[name]
+            ctx.flush(self.model.arena.ensure_grad()[s:e])
 
     # ------------------------------------------------------------------ parameters
     def P(self, name: str) -> torch.Tensor:
@@ -278,6 +296,7 @@ class DenoiserEngine:
         fsum = self.buf("fsum", (B, self.U), f32)
         fsum.zero_()
         ops.uhead_fwd(xt, self._uhead_w(), fsum, self.U)
+        self._det_flush(fsum)
         ops.uhead_tail(fsum, self.ws.t["umod"], self.P("u_out.weight"), self.P("u_out.bias"), u, L, self.model.u_scale)
 
     def _v_of(self, qkv: torch.Tensor) -> torch.Tensor:
@@ -372,6 +391,9 @@ class DenoiserEngine:
         assert self.train
         B, L, M, D, dh, Hf, Hp, A = self.B, self.L, self.M, self.D, self.dh, self.Hf, self.Hp, self.A
         f32 = torch.float32
+        dctx = det.context(self.model.arena.data.device)
+        if dctx is not None:
+            dctx.register(self.model.arena.ensure_grad())
         tab = self.ws.t["rope"]
         cg, a = self.ws.t["cg"], self.ws.t["a"]
         # residual-stream gradient and scratch
@@ -396,6 +418,7 @@ class DenoiserEngine:
         ops.uhead_bwd(xt, self._uhead_w(), dfm, self._uhead_w(grads=True), self.U)
         ops.linear_small_bwd(cg, self.P("u_mod.weight"), None, dmod, self.buf("d.lin_pre_umod", (B, 2 * self.U), f32),
                              self.G("u_mod.weight"), self.G("u_mod.bias"), dcg, False, OD_ACT_NONE)
+        self._det_flush_segment("tail")
         if reducer is not None:
             reducer.segment_done("tail")
 
@@ -436,10 +459,12 @@ class DenoiserEngine:
             ops.rmsnorm_film_bwd(t[f"x_in.{i}"], t[f"inv1.{i}"], ssg1, dtmp, dx, dssg1, B, L)
             # ---- the two modulation linears of this layer
             lp = self.buf("d.lin_pre_ssg", (B, 3 * D), f32)
+            self._det_flush(dssg1, dssg2)
             ops.linear_small_bwd(cg, self.P(p + "ssg2.weight"), None, dssg2, lp, self.G(p + "ssg2.weight"),
                                  self.G(p + "ssg2.bias"), dcg, True, OD_ACT_NONE)
             ops.linear_small_bwd(cg, self.P(p + "ssg1.weight"), None, dssg1, lp, self.G(p + "ssg1.weight"),
                                  self.G(p + "ssg1.bias"), dcg, True, OD_ACT_NONE)
+            self._det_flush_segment(f"layer{i}")
             if reducer is not None:
                 reducer.segment_done(f"layer{i}")
 
@@ -447,9 +472,11 @@ class DenoiserEngine:
         da_pre = self.buf("d.a_pre", (self.Ma, A))
         ops.silu_bwd(self.ws.t["a_pre"], da, da_pre)
         ops.gemm_tn(da_pre, self.ws.t["a_t"], self.G("proj_audio.0.weight"), dbias=self.G("proj_audio.0.bias"))
+        self._det_flush(dcg)
         ops.linear_small_bwd(style, self.P("proj_style.0.weight"), self.ws.t["cg_pre"], dcg,
                              self.buf("d.lin_pre_style", (B, self.Cg), f32), self.G("proj_style.0.weight"),
                              self.G("proj_style.0.bias"), None, False, OD_ACT_SILU)
+        self._det_flush_segment("head")
         if reducer is not None:
             reducer.segment_done("head")
         # The fused attention backward draws its jobs from one queue per XCD and needs every XCD to run at least one of its workgroups (observed

@@ -188,7 +188,9 @@ class _TrainLossFn(torch.autograd.Function):
         eng.conditioning(h, s)
         eng.pred(xt, u, v)
         out = torch.empty(4, dtype=torch.float32, device=dev)
+        eng._det_flush(dsq)                              # (OD_DETERMINISTIC: make_xt's per-sample sums, read by loss_grad)
         ops.loss_grad(xt, x1, u, v, dsq, dv, sums, model.c0, osl_w, del_w)
+        eng._det_flush(sums)
         ops.loss_finalize(sums, dsq, u, out, du, model.c0, osl_w, del_w)
         ctx.model, ctx.style, ctx.nparams = model, s, len(params)
         return out[0], out[1], out[2], out[3]

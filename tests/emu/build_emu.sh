@@ -7,7 +7,7 @@ OUT=libod_emu.so
 mkdir -p build
 OBJS=""
 PIDS=""
-for s in gemm rowops misc heads optim attn attn_bwd_fused style latent comm calib; do
+for s in gemm rowops misc heads optim attn attn_bwd_fused style latent comm calib det; do
   o=build/$s.o
   if [ ! -f "$o" ] || [ "$CS/$s.hip" -nt "$o" ] || [ "$CS/od_common.h" -nt "$o" ] || [ "$CS/od_tiles.h" -nt "$o" ] || [ "$CS/od_api_internal.h" -nt "$o" ] || [ ../../include/osu_dreamer_hip.h -nt "$o" ] || [ emu_hip.h -nt "$o" ]; then
     rm -f "$o"

@@ -314,6 +314,43 @@ def test_full_batch_step_is_mean_of_sub_batches(dev, B, L, parts):
           f"worst segment rel-L2 {worst:.2e} (same step twice: {noise:.2e})")
 
 
+def test_deterministic_full_batch_step_is_bit_identical(dev):
+    """OD_DETERMINISTIC at the bench shape (32 x 8192, bf16): two runs of the same training step — loss, the whole gradient arena, the clip norm
+    and the weights after the optimizer step — are BIT-identical (the plain step differs by ~6e-5 rel-L2 from run to run: fp32 atomics), and the
+    deterministic gradients sit inside that same noise of the plain ones."""
+    import bench
+    from osu_dreamer_amd import det
+    h, z, s, _ = bench.synthetic_batch(32, 8192, dev, seed=32)
+    g = torch.Generator(device=dev).manual_seed(33)
+    t = torch.rand(32, device=dev, generator=g) * 0.8 + 0.1
+    x0 = torch.randn(32, 6, 8192, device=dev, generator=g)
+    res = {}
+    try:
+        for mode in ("plain", "plain2", "det", "det2"):
+            det.force(mode.startswith("det"))
+            tr = bench.make_trainer(dev, seed=31)
+            model = tr.diffusion
+            model.compute_dtype = torch.bfloat16
+            opt = tr.configure_optimizers()["optimizer"]
+            opt.max_grad_norm = 1.0
+            opt.zero_grad()
+            loss, _ = tr(model, h, z, s, None, t=t, x0=x0)
+            loss.backward()
+            gr = model.arena.grad.clone()
+            opt.step()
+            torch.cuda.synchronize()
+            res[mode] = (float(loss.detach()), gr, model.arena.data.clone(), float(opt.gnorm_sq))
+            del tr, model, opt
+    finally:
+        det.force(None)
+    noise = rel(res["plain2"][1], res["plain"][1])
+    assert res["det"][0] == res["det2"][0] and res["det"][3] == res["det2"][3]
+    assert torch.equal(res["det"][1], res["det2"][1]) and torch.equal(res["det"][2], res["det2"][2])
+    d_vs_p = rel(res["det"][1], res["plain"][1])
+    assert d_vs_p <= 3 * noise + 1e-5, (d_vs_p, noise)
+    print(f"deterministic step twice: bit-identical; vs the plain step {d_vs_p:.2e} rel-L2 (plain step twice: {noise:.2e}; same bits: {bool(torch.equal(res['plain'][1], res['plain2'][1]))})")
+
+
 def test_sampler_graph_equals_eager_config3(dev):
     import bench
     from osu_dreamer_amd.model import DiffusionModel

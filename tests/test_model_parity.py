@@ -357,6 +357,47 @@ def test_f16_attention_in_the_step(dev):
     assert med <= 1.1 and worst <= 2.0
 
 
+def test_deterministic_mode_matches_the_plain_step(dev):
+    """OD_DETERMINISTIC (osu_dreamer_amd/det.py): the same kernels accumulate 2^40-scaled integers into 64-bit shadows instead of fp32 atomics and
+    the engine folds them in before each destination's first reader.  The step must be the plain step to fp32 rounding — loss, every gradient,
+    two optimizer steps — and leave every shadow empty; a second run of the deterministic step must be bit-identical to the first.  (On the
+    GPU, where the atomics' order really varies: tests/test_full_size.py::test_deterministic_full_batch_step_is_bit_identical.)"""
+    from osu_dreamer_amd import det
+    d = O.Dims(global_cond_dim=64, backbone_dim=128, n_heads=2, head_dim=64, depth=2, expand=2, radius=1, u_head_dim=16)
+    P = O.init_params(d, seed=21)
+    data = O.synthetic_batch(d, 3, 150, seed=22)
+    out = {}
+    try:
+        for mode in ("plain", "det", "det2"):
+            det.force(mode != "plain")
+            tr = make_trainer(d, P, dev)
+            model = tr.diffusion
+            model.compute_dtype = torch.bfloat16
+            dd = {k: v.to(dev) for k, v in data.items()}
+            opt = tr.configure_optimizers()["optimizer"]
+            opt.max_grad_norm = 1.0
+            losses = []
+            for _ in range(2):
+                opt.zero_grad()
+                loss, _ = tr(model, dd["h"], dd["z"], dd["s"], None, t=dd["t"], x0=dd["x0"])
+                loss.backward()
+                g1 = model.arena.grad.detach().cpu().clone()
+                opt.step()
+                losses.append(float(loss.detach()))
+            out[mode] = (losses, g1, model.arena.data.detach().cpu().clone())
+            if mode != "plain":
+                ctx = det.context(dev)
+                assert len(ctx.ranges) >= 6
+                for t, sh in ctx.ranges.values():
+                    assert int(sh.abs().max()) == 0                   # every shadow was folded in
+    finally:
+        det.force(None)
+    assert torch.equal(out["det"][1], out["det2"][1]) and torch.equal(out["det"][2], out["det2"][2]) and out["det"][0] == out["det2"][0]
+    assert out["det"][0] == pytest.approx(out["plain"][0], rel=1e-6)
+    assert rel_l2(out["det"][1], out["plain"][1]) < 2e-6
+    assert rel_l2(out["det"][2], out["plain"][2]) < 1e-6
+
+
 def test_failed_attention_backward_is_caught_in_every_step(dev, monkeypatch):
     """The fused attention backward's sticky error word is folded into EVERY optimizer step on the device (no host round trip): after a good
     first step, a launch on a workspace whose write numbers were damaged ends with status 3 and NaN dq — the gradient norm turns NaN, the

@@ -12,7 +12,7 @@ name=$1; flags=$2; shift 2 || true
 srcs=${@:-attn}
 out=../../gpurun_variants; mkdir -p $out/obj_$name
 objs=""
-for s in gemm rowops misc heads optim attn attn_bwd_fused style latent comm calib; do
+for s in gemm rowops misc heads optim attn attn_bwd_fused style latent comm calib det; do
   file=""
   for spec in $srcs; do
     [ "$spec" = "$s" ] && file=$s.hip
