@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
         }
     }
     const int col = lane & 15, g2 = lane >> 4;
+    long long* const dw_shadow = od_det_find(det, dW);
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -1013,7 +1014,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wm * 64 + i * 16 + g2 * 4 + r, k = k0 + wn * 64 + j * 16 + col;
-                if (n < N && k < K) od_red_add(det, dW + (size_t)n * lddw + k, acc[i][j][r]);
+                if (n < N && k < K) od_red_add_at(dw_shadow, dW, (size_t)n * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
         __syncthreads();
@@ -1139,6 +1140,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
         __syncthreads();
     }
     if (do_bias) atomicAdd(&sred[tid & 255], bsum);
+    long long* const dw_shadow = od_det_find(det, dW);
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wm * 128 + i * 16 + g * 4 + r, k = k0 + wn * 64 + j * 16 + x;
-                if (n < N && k < K) od_red_add(det, dW + (size_t)n * lddw + k, acc[i][j][r]);
+                if (n < N && k < K) od_red_add_at(dw_shadow, dW, (size_t)n * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
         __syncthreads();
@@ -1164,6 +1166,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
 //   MFMA  88..119   half 0 of slab st + 1 from the other stage -> register set 0
 // against the 8-wave kernel's read-everything / 32-MFMAs / barrier per half (0.75 transpose reads per MFMA; here 0.5).  Same tile -> (n0, k0,
 // M-split) maps, same LDS image (512-byte rows, tn512_off), same fp32-atomic epilogue (od_red_add) and bias column sums as gemm_tn_big_kernel.
+// every lambda of the kernel must be inlined: one that is not keeps its by-reference captures (the 256 accumulators!) in scratch memory
+#if defined(OD_EMU)
+#define TNW4_INLINE
+#else
+#define TNW4_INLINE __attribute__((always_inline))
+#endif
 #ifndef OD_TNW4_X
 #define OD_TNW4_X 0        // timing experiments only (wrong results): 2 no loop fragment reads, 16 no fetch
 #endif
@@ -1230,19 +1238,30 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
     od_frag<bf16_t> fa[2][8], fb[2][8];                    // [half = register set][tile]: fa from the G slab (n), fb from the A slab (k)
     // read r of a half's 32: r = 2 t + e -> transpose read e of fragment t (t < 8: fa, else fb), in the order the MFMAs first use them
     // (MFMA n of a half = (i = n >> 3, j = n & 7): fa[0] and all eight fb first)
-    auto rd_one = [&](const unsigned char* st, int u, int r) {
+    // LDS byte addresses of the transpose-read chunks, one register per 16-column fragment tile (0..7: the wave's G columns, 8..15: its A
+    // columns): row 4 g + (x >> 2) of the stage — + 32 u + 16 e rows are multiples of 16, which leave tn512_off's swizzle key (row & 15) alone
+    // and fold into the instruction's offset field —, 32-byte slot (tile index) ^ key, 8 (x & 3) bytes in.  They point at the stage being
+    // READ and flip to the other one (^ 65536) in the middle of every slab, between the last read of this stage and the first of the next.
+    unsigned offs[16];
+    {
+        const int rb = 4 * g + (x >> 2);
+        const unsigned base = od_lds_addr(smem);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            offs[t] = base + (unsigned)(rb * 512 + (((wm * 8 + t) ^ rb) << 5) + 8 * (x & 3));
+            offs[8 + t] = base + (unsigned)(32768 + rb * 512 + (((wn * 8 + t) ^ rb) << 5) + 8 * (x & 3));
+        }
+    }
+    auto rd_one = [&](int u, int r) TNW4_INLINE {
         const int t = r >> 1, e = r & 1;
         const int seq = t == 0 ? 0 : t < 9 ? t + 7 : t - 8;            // fragment order: fa[0], fb[0..7], fa[1..7]  -> index into (fa: 0..7, fb: 8..15)
         const bool is_b = seq >= 8;
         const int idx = seq & 7;
-        const unsigned char* base = is_b ? st + 32768 : st;
-        const int cc = (is_b ? wn : wm) * 128 + idx * 16;
-        const int cb = (cc + 4 * (x & 3)) * 2, rr = 32 * u + 4 * g + (x >> 2) + 16 * e;
-        const s16x4 v4 = od_lds_tr_read((const bf16_t*)(base + tn512_off(rr, cb)));
+        const s16x4 v4 = od_lds_tr_read_at(offs[seq] + (unsigned)((32 * u + 16 * e) * 512));
         od_frag<bf16_t>& f = is_b ? fb[u][idx] : fa[u][idx];
         f.v[4 * e] = v4[0]; f.v[4 * e + 1] = v4[1]; f.v[4 * e + 2] = v4[2]; f.v[4 * e + 3] = v4[3];
     };
-    auto mma_one = [&](int u, int n) {
+    auto mma_one = [&](int u, int n) TNW4_INLINE {
         const int i = n >> 3, j = n & 7;
 #if defined(OD_EMU)
         acc[i][j] = od_mma(fa[u][i], fb[u][j], acc[i][j]);
@@ -1250,11 +1269,19 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[u][i].v), "v"(fb[u][j].v));
 #endif
     };
-    // bias tiles: column sums of the G slab, 16-byte row pieces (thread -> 8 columns x 8 rows per slab), before the stage is released
+    // bias tiles: column sums of the G slab in 16-byte row pieces.  A thread owns 8 columns and the rows (tid >> 5) + 8 p + 16 q (p = 0, 1;
+    // q = 0..3): rows 16 apart share the swizzle key, so q enters as an immediate and two address registers serve the eight reads of a slab.
+    // (They follow the fragment addresses to the other stage in the middle of every slab.)
     float bs[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) bs[e] = 0.f;
-    const int bcol8 = (tid & 31) * 8, brow0 = (tid >> 5) * 8;
+    const int bcol8 = (tid & 31) * 8;
+    unsigned boff[2];
+#pragma unroll
+    for (int p_ = 0; p_ < 2; p_++) {
+        const int rk = (tid >> 5) + 8 * p_;
+        boff[p_] = od_lds_addr(smem) + (unsigned)(rk * 512 + (((((tid & 31) >> 1)) ^ rk) << 5) + (tid & 1) * 16);
+    }
 
     // prologue: slabs 0 and 1 in flight, slab 0 landed, its half-0 fragments in register set 0
 #pragma unroll
@@ -1267,11 +1294,9 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
     OD_WAIT_VMCNT(16);
     od_barrier_raw();
 #pragma unroll
-    for (int r = 0; r < 32; r++) rd_one(smem, 0, r);
+    for (int r = 0; r < 32; r++) rd_one(0, r);
 
-    auto slab = [&](int st, const int xs) {
-        const unsigned char* X = smem + xs * STG;
-        const unsigned char* Y = smem + (xs ^ 1) * STG;
+    auto slab = [&](int st, const int xs) TNW4_INLINE {
         const unsigned dst = lds_mine + (unsigned)xs * STG;
         const unsigned so = (unsigned)(st + 2) * 64u * (unsigned)ld * 2u;      // past the last slab: beyond the descriptor, zeros
 #pragma clang loop unroll(full)
@@ -1281,7 +1306,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
 #pragma unroll
                     for (int rr = 0; rr < 8; rr++) {
                         float v8[8];
-                        od_ld8((const bf16_t*)(X + tn512_off(brow0 + rr, bcol8 * 2)), v8);
+                        od_lds_ld8_at(boff[rr & 1] + (unsigned)((rr >> 1) * 16 * 512), v8);
 #pragma unroll
                         for (int e = 0; e < 8; e++) bs[e] += v8[e];
                     }
@@ -1297,18 +1322,21 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
             const int q = (n - 33) / 3;
             if (d) od_dma_set_dst(dst + (unsigned)q * 1024u);
             if (!(OD_TNW4_X & 2)) {
-                if (n < 32) rd_one(X, 1, n);
-                if (n >= 88 && n < 120) rd_one(Y, 0, n - 88);
+                if (n < 32) rd_one(1, n);
+                if (n >= 88 && n < 120) rd_one(0, n - 88);
             }
+            if (n >= 40 && n < 56) offs[n - 40] ^= 65536u;                     // the read addresses move to the other stage
+            if (n == 56) { boff[0] ^= 65536u; boff[1] ^= 65536u; }
             mma_one(n >> 6, n & 63);
             if (d) od_buffer_lds16_m0(srd, voff8[q & 7], so + (unsigned)(q >> 3) * half_stride);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // slabs in pairs, unconditionally (an odd count computes one slab of zeros: rows past `me` lie beyond the descriptor) — with a branch
+    // between the two instances the register allocator kept the accumulators in VGPRs and copied them to AGPRs in front of every MFMA
     for (int st = 0; st < nslab; st += 2) {
         slab(st, 0);
-        if (st + 1 < nslab) slab(st + 1, 1);
-        else break;
+        slab(st + 1, 1);
     }
 #if !defined(OD_EMU)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the epilogue reads the accumulators
@@ -1324,6 +1352,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
             }
         }
     }
+    long long* const dw_shadow = od_det_find(det, dW);
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -1331,7 +1360,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wm * 128 + i * 16 + g * 4 + r, k = k0 + wn * 128 + j * 16 + x;
-                if (n < N && k < K) od_red_add(det, dW + (size_t)n * lddw + k, acc[i][j][r]);
+                if (n < N && k < K) od_red_add_at(dw_shadow, dW, (size_t)n * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
         __syncthreads();

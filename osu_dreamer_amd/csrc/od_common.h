@@ -308,6 +308,9 @@ __device__ __forceinline__ s16x4 od_lds_tr_read(const bf16_t* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 #endif
+// the same from a raw LDS byte address (od_lds_addr of the array + offset): `addr + constant` folds into the instruction's offset field, so one
+// lane-dependent register serves every row / stage variant of a fragment's chunk (declared after od_lds_addr, below)
+__device__ __forceinline__ s16x4 od_lds_tr_read_at(unsigned addr);
 
 __device__ __forceinline__ f32x4 od_mma(const od_frag<bf16_t>& a, const od_frag<bf16_t>& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
@@ -435,6 +438,29 @@ __device__ __forceinline__ void od_buffer_lds16_at_nt(od_srd_t r, unsigned voff,
 __device__ __forceinline__ int od_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 #endif
 
+#if defined(OD_EMU)
+__device__ __forceinline__ s16x4 od_lds_tr_read_at(unsigned addr) { return emu::ds_read_tr16_b64((const unsigned short*)(emu::dyn_smem() + (long)(int)addr)); }
+#else
+__device__ __forceinline__ s16x4 od_lds_tr_read_at(unsigned addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)addr);
+}
+#endif
+
+// 8 bf16 from a raw LDS byte address -> 8 floats
+#if defined(OD_EMU)
+__device__ __forceinline__ void od_lds_ld8_at(unsigned addr, float (&v)[8]) { od_ld8((const bf16_t*)(emu::dyn_smem() + (long)(int)addr), v); }
+#else
+__device__ __forceinline__ void od_lds_ld8_at(unsigned addr, float (&v)[8]) {
+    const u32x4 r = *(const __attribute__((address_space(3))) u32x4*)(size_t)addr;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        union { uint32_t u; float f; } lo, hi;
+        lo.u = r[i] << 16; hi.u = r[i] & 0xffff0000u;
+        v[2 * i] = lo.f; v[2 * i + 1] = hi.f;
+    }
+}
+#endif
+
 // Hand-placed synchronisation for kernels that keep LDS-DMA in flight across workgroup barriers: __syncthreads() would drain
 // the VMEM counter (an LDS-DMA is a pending LDS write), so those kernels use a bare s_barrier and counted vmcnt waits.
 #if defined(OD_EMU)
@@ -477,6 +503,23 @@ __device__ __forceinline__ void od_red_add(const OdDetTable* det, float* p, floa
         }
     }
     atomicAdd(p, v);
+}
+// The same for an epilogue that adds MANY elements of one matrix (the weight-gradient GEMMs: 256 accumulator registers per lane): the range
+// is looked up once, the per-element code is a uniform branch and one atomic (a table walk per element would not unroll, and an accumulator
+// array that is indexed by a loop variable lives in scratch memory).
+__device__ __forceinline__ long long* od_det_find(const OdDetTable* det, const float* base) {
+    if (det) {
+        const int n = det->n;
+        for (int i = 0; i < n; i++) {
+            const long long off = base - det->r[i].base;
+            if (off >= 0 && off < det->r[i].count) return det->r[i].shadow + off;
+        }
+    }
+    return nullptr;
+}
+__device__ __forceinline__ void od_red_add_at(long long* shadow, float* base, size_t off, float v) {
+    if (shadow && fabsf(v) < 8388608.f) atomicAdd((unsigned long long*)(shadow + off), (unsigned long long)od_fix(v));
+    else atomicAdd(base + off, v);
 }
 // Block-level sums in LDS: always fixed point (ds_add_u64), so the order the waves of a block arrive in never shows either.  A value the
 // format cannot hold sets the block's `bad` word instead; od_lds_unfix then hands back NaN for every slot of that block.
