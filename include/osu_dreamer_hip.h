@@ -74,6 +74,11 @@ int od_gemm_nt_qkrope_split(int dtype, const void* A, int lda, const void* W, in
  * — autograd weight and bias gradients of the above, G read once. */
 int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M, int N,
                int K, void* stream);
+/* the same for a G whose N columns come in blocks of n_block columns with only the first n_valid of each live (the packed SwiGLU projection:
+ * Hf = 1365 padded to 1408, v then g): output row of column n = (n / n_block) * n_valid + n % n_block, padding columns dropped — one launch
+ * over the padded width writes the un-padded (2 Hf, K) gradient (n_block = 0: od_gemm_tn).  replaces: autograd of swiglu.py:21. */
+int od_gemm_tn_blocks(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M, int N,
+                      int K, int n_block, int n_valid, void* stream);
 /* out[N] (fp32) += column sums of G[M,N]        — autograd bias gradient. */
 int od_colsum(int dtype, const void* G, int ldg, float* out, int M, int N, void* stream);
 /* dst[Np,Kp] (dtype, zero padded) = src[N,K] fp32 (transpose=0) or dst[Kp,Np] = src^T (transpose=1);

@@ -109,6 +109,20 @@ struct RopeEpi {
 };
 constexpr int OD_EPI_QKROPE = 2;
 
+// od_gemm_tn_blocks: the N columns of G come in blocks of `block` columns of which the first `valid` are live (the SwiGLU hidden width 1365
+// padded to 1408, twice: v then g); output row of column n = (n / block) * valid + n % block, the padding columns are dropped.  block = 0: identity.
+struct TnRowMap { int block, valid; };
+__device__ __forceinline__ bool tn_map_row(const TnRowMap rm, int n, int N, int& out) {
+    out = n;
+    if (n >= N) return false;
+    if (rm.block) {
+        const int q = n / rm.block, r = n - q * rm.block;
+        out = q * rm.valid + r;
+        return r < rm.valid;
+    }
+    return true;
+}
+
 // WMT = 16-row MFMA tiles per wave along m: 4 -> 128 x 128 block tile, 2 -> 64 x 128 (twice the workgroups, for
 // launches whose 128-row tiling would leave CUs idle: the sampler's M = B*L = 4460 against N = 512)
 // LDS stages of gemm_nt_kernel and its dynamic LDS size.  At the sampler's sizes (M = 4460: one workgroup per CU, 16-44 k-tiles of ~0.15 us of
@@ -853,7 +867,7 @@ __device__ __forceinline__ void tn_frag(od_frag<float>&, const unsigned char*, i
 template <class T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ A, int lda,
                                                       float* __restrict__ dW, int lddw, float* __restrict__ dbias,
-                                                      int M, int N, int K, int m_per_block, const OdDetTable* __restrict__ det) {
+                                                      int M, int N, int K, int m_per_block, const OdDetTable* __restrict__ det, TnRowMap rm) {
     constexpr bool TR = sizeof(T) == 2;
     constexpr int BR = 128 / (int)sizeof(T);  // reduction rows per slab (64 bf16 / 32 f32)
     constexpr int CH = 16 / (int)sizeof(T);
@@ -1014,11 +1028,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wm * 64 + i * 16 + g2 * 4 + r, k = k0 + wn * 64 + j * 16 + col;
-                if (n < N && k < K) od_red_add_at(dw_shadow, dW, (size_t)n * lddw + k, acc[i][j][r]);
+                int no;
+                if (tn_map_row(rm, n, N, no) && k < K) od_red_add_at(dw_shadow, dW, (size_t)no * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
         __syncthreads();
-        if (tid < 128 && n0 + tid < N) od_red_add(det, dbias + n0 + tid, sred[tid]);       // (the bf16 path: two contributions per column — a + b = b + a)
+        int no;
+        if (tid < 128 && tn_map_row(rm, n0 + tid, N, no)) od_red_add(det, dbias + no, sred[tid]);       // (the bf16 path: two contributions per column — a + b = b + a)
     }
 }
 
@@ -1038,7 +1054,7 @@ __device__ __forceinline__ void tn512_frag(od_frag<bf16_t>& f, const unsigned ch
 __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A, int lda,
                                                              float* __restrict__ dW, int lddw, float* __restrict__ dbias,
                                                              int M, int N, int K, int m_per_block, int xcd_full,
-                                                             const OdDetTable* __restrict__ det) {
+                                                             const OdDetTable* __restrict__ det, TnRowMap rm) {
     const int xcd_order = xcd_full & 3;
     constexpr int STG = 65536;                 // G slab [64][256] 32 KiB + A slab [64][256] 32 KiB
     OD_DYN_SMEM(smem);
@@ -1148,11 +1164,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wm * 128 + i * 16 + g * 4 + r, k = k0 + wn * 64 + j * 16 + x;
-                if (n < N && k < K) od_red_add_at(dw_shadow, dW, (size_t)n * lddw + k, acc[i][j][r]);
+                int no;
+                if (tn_map_row(rm, n, N, no) && k < K) od_red_add_at(dw_shadow, dW, (size_t)no * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
         __syncthreads();
-        if (tid < 256 && n0 + tid < N) od_red_add(det, dbias + n0 + tid, sred[tid]);
+        int no;
+        if (tid < 256 && tn_map_row(rm, n0 + tid, N, no)) od_red_add(det, dbias + no, sred[tid]);
     }
 }
 
@@ -1172,13 +1190,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
 #else
 #define TNW4_INLINE __attribute__((always_inline))
 #endif
+#ifndef OD_TNW4_DMA_EVERY
+#define OD_TNW4_DMA_EVERY 3       // a DMA piece behind every n-th MFMA from 33 on
+#endif
+#ifndef OD_TNW4_L_AT
+#define OD_TNW4_L_AT 88           // LANDED barrier in front of this MFMA; the next slab's half-0 reads follow it, one per MFMA
+#endif
 #ifndef OD_TNW4_X
 #define OD_TNW4_X 0        // timing experiments only (wrong results): 2 no loop fragment reads, 16 no fetch
 #endif
 __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A, int lda,
                                                             float* __restrict__ dW, int lddw, float* __restrict__ dbias,
                                                             int M, int N, int K, int m_per_block, int xcd_full,
-                                                            const OdDetTable* __restrict__ det) {
+                                                            const OdDetTable* __restrict__ det, TnRowMap rm) {
     const int xcd_order = xcd_full & 3;
     constexpr int STG = 65536;                 // G slab [64][256] 32 KiB + A slab [64][256] 32 KiB
     OD_DYN_SMEM(smem);
@@ -1314,16 +1338,17 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
                 OD_WAIT_LGKMCNT(0);
                 od_barrier_raw();
             }
-            if (n == 88) {
+            static_assert(33 + 15 * OD_TNW4_DMA_EVERY < OD_TNW4_L_AT && OD_TNW4_L_AT + 32 <= 128 && OD_TNW4_L_AT >= 56, "schedule does not fit the slab");
+            if (n == OD_TNW4_L_AT) {
                 OD_WAIT_VMCNT(16);
                 od_barrier_raw();
             }
-            const bool d = n >= 33 && n < 33 + 48 && (n - 33) % 3 == 0;         // 16 pieces at MFMAs 33, 36, ..., 78
-            const int q = (n - 33) / 3;
+            const bool d = n >= 33 && n < 33 + 16 * OD_TNW4_DMA_EVERY && (n - 33) % OD_TNW4_DMA_EVERY == 0;         // 16 pieces at MFMAs 33, 36, ..., 78
+            const int q = (n - 33) / OD_TNW4_DMA_EVERY;
             if (d) od_dma_set_dst(dst + (unsigned)q * 1024u);
             if (!(OD_TNW4_X & 2)) {
                 if (n < 32) rd_one(1, n);
-                if (n >= 88 && n < 120) rd_one(0, n - 88);
+                if (n >= OD_TNW4_L_AT && n < OD_TNW4_L_AT + 32) rd_one(0, n - OD_TNW4_L_AT);
             }
             if (n >= 40 && n < 56) offs[n - 40] ^= 65536u;                     // the read addresses move to the other stage
             if (n == 56) { boff[0] ^= 65536u; boff[1] ^= 65536u; }
@@ -1360,11 +1385,13 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const bf16_t* __rest
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int n = n0 + wm * 128 + i * 16 + g * 4 + r, k = k0 + wn * 128 + j * 16 + x;
-                if (n < N && k < K) od_red_add_at(dw_shadow, dW, (size_t)n * lddw + k, acc[i][j][r]);
+                int no;
+                if (tn_map_row(rm, n, N, no) && k < K) od_red_add_at(dw_shadow, dW, (size_t)no * lddw + k, acc[i][j][r]);
             }
     if (do_bias) {
         __syncthreads();
-        if (n0 + tid < N) od_red_add(det, dbias + n0 + tid, sred[tid]);
+        int no;
+        if (tn_map_row(rm, n0 + tid, N, no)) od_red_add(det, dbias + no, sred[tid]);
     }
 }
 
@@ -1458,7 +1485,7 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
 }
 
 template <class T>
-int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, float* dbias, int M, int N, int K, hipStream_t st) {
+int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, float* dbias, int M, int N, int K, hipStream_t st, TnRowMap rm = TnRowMap{0, 0}) {
     constexpr int BR = 128 / (int)sizeof(T);
     if constexpr (sizeof(T) == 2) {
         const int tiles2 = ((N + 255) / 256) * ((K + 255) / 256);
@@ -1508,9 +1535,9 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
                 grid_tn = xcd_order ? ((sp + 7) / 8) * 8 * tiles2 : tiles2 * sp;
             static const int tn_w4 = od_env_int("OD_TN_W4", 1);                  // (0: the 8-wave kernel; A/B)
             if (tn_w4)
-                OD_LAUNCH_DYN(gemm_tn_w4_kernel, dim3(grid_tn), dim3(256), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active());
+                OD_LAUNCH_DYN(gemm_tn_w4_kernel, dim3(grid_tn), dim3(256), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active(), rm);
             else
-                OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(grid_tn), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active());
+                OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(grid_tn), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active(), rm);
             OD_CHECK_LAUNCH();
             return 0;
         }
@@ -1525,7 +1552,7 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
     mpb = ((mpb + BR - 1) / BR) * BR;
     if (mpb < 4 * BR) mpb = 4 * BR;
     splits = (M + mpb - 1) / mpb;
-    OD_LAUNCH((gemm_tn_kernel<T>), dim3(tiles * splits), dim3(256), 0, st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb, od_det_active());
+    OD_LAUNCH((gemm_tn_kernel<T>), dim3(tiles * splits), dim3(256), 0, st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb, od_det_active(), rm);
     OD_CHECK_LAUNCH();
     return 0;
 }
@@ -1614,14 +1641,20 @@ extern "C" int od_gemm_nt_qkrope_split(int dtype, const void* A, int lda, const 
     return 0;
 }
 
-extern "C" int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M,
-                          int N, int K, void* stream) {
-    if (M <= 0 || N <= 0 || K <= 0) return OD_ERR_ARG;
+extern "C" int od_gemm_tn_blocks(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M,
+                                 int N, int K, int n_block, int n_valid, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || n_block < 0 || n_valid < 0 || n_valid > n_block) return OD_ERR_ARG;
     const int ch = dtype == OD_BF16 ? 8 : 4;
     if (ldg % ch || lda % ch) return OD_ERR_ALIGN;
-    if (dtype == OD_BF16) return launch_tn<bf16_t>((const bf16_t*)G, ldg, (const bf16_t*)A, lda, dW, lddw, dbias, M, N, K, (hipStream_t)stream);
-    if (dtype == OD_F32) return launch_tn<float>((const float*)G, ldg, (const float*)A, lda, dW, lddw, dbias, M, N, K, (hipStream_t)stream);
+    const TnRowMap rm{n_block, n_block ? n_valid : 0};
+    if (dtype == OD_BF16) return launch_tn<bf16_t>((const bf16_t*)G, ldg, (const bf16_t*)A, lda, dW, lddw, dbias, M, N, K, (hipStream_t)stream, rm);
+    if (dtype == OD_F32) return launch_tn<float>((const float*)G, ldg, (const float*)A, lda, dW, lddw, dbias, M, N, K, (hipStream_t)stream, rm);
     return OD_ERR_ARG;
+}
+
+extern "C" int od_gemm_tn(int dtype, const void* G, int ldg, const void* A, int lda, float* dW, int lddw, float* dbias, int M,
+                          int N, int K, void* stream) {
+    return od_gemm_tn_blocks(dtype, G, ldg, A, lda, dW, lddw, dbias, M, N, K, 0, 0, stream);
 }
 
 extern "C" int od_colsum(int dtype, const void* G, int ldg, float* out, int M, int N, void* stream) {

@@ -104,15 +104,18 @@ def gemm_nt_qkrope_split(A, W, bias, C, qk_out, wq, wk, table, L, H, hd, eps, x3
                                        _ld(qk_out), qk_code, M, N, K, _p(wq), _p(wk), _p(table), L, H, hd, eps, q_scale, _stream(A))
 
 
-def gemm_tn(G, A, dW, n_cols=None, k_cols=None, dbias=None):
+def gemm_tn(G, A, dW, n_cols=None, k_cols=None, dbias=None, n_block=0, n_valid=0):
     """dW[N,K] += G[:, :N]^T A[:, :K] (and dbias[N] += column sums of G);  dW is any fp32 tensor
-    viewed as [N, K] rows."""
+    viewed as [N, K] rows.  `n_block` / `n_valid`: G's columns come in blocks of n_block of which the first n_valid are live (the padded
+    SwiGLU width); dW / dbias are then the UN-padded (N / n_block * n_valid) rows."""
     M = G.shape[0]
     N = n_cols if n_cols is not None else G.shape[1]
     K = k_cols if k_cols is not None else A.shape[1]
-    assert dW.dtype == torch.float32 and dW.is_contiguous() and dW.numel() == N * K
+    rows = N if not n_block else (N // n_block) * n_valid
+    assert not n_block or N % n_block == 0
+    assert dW.dtype == torch.float32 and dW.is_contiguous() and dW.numel() == rows * K
     _f32(dbias)
-    _lib.lib().od_gemm_tn(dt_code(G.dtype), _p(G), _ld(G), _p(A), _ld(A), _p(dW), K, _p(dbias), M, N, K, _stream(G))
+    _lib.lib().od_gemm_tn_blocks(dt_code(G.dtype), _p(G), _ld(G), _p(A), _ld(A), _p(dW), K, _p(dbias), M, N, K, n_block, n_valid, _stream(G))
 
 
 def colsum(G, out, n_cols=None):

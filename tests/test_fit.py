@@ -64,3 +64,29 @@ def test_fit_denoiser_synthetic(dev, tmp_path):
     assert trainer2.global_step >= 4
     lines = [json.loads(l) for l in open(tmp_path / "run" / "metrics.jsonl")]
     assert any(l.get("step") == 4 for l in lines)
+
+
+def test_fit_precision_16_mixed_runs_the_half_attention_core(dev, tmp_path):
+    """`precision: 16-mixed` (the fp16 option of the trainer key model.yml:12; BASELINE configs[4]): bf16 compute with the attention core on
+    IEEE-half operands, training and validation, through the same fit shell."""
+    cfg = _cfg(False)
+    cfg["model"].update(emb_dim=6, a_dim=16, style_dim=8)
+    cfg["model"]["diffusion_args"] = dict(global_cond_dim=32, u_head_dim=16, backbone_dim=128,
+                                          backbone_args=dict(head_dim=64, n_heads=2, depth=2, expand=2, radius=1))
+    data_dir = tmp_path / "data"
+    write_synthetic_dataset(str(data_dir), n_maps=6, frames=96, a_dim=16, emb_dim=6, style_dim=8, seed=2)
+    cfg["data"].update(data_path=str(data_dir), seq_len=48, batch_size=2, num_workers=0, shuffle_buffer_size=1, max_val_count=64, max_per_map=-1)
+    cfg["trainer"].update(max_steps=2, log_every_n_steps=1, val_check_interval=2, limit_val_batches=1,
+                          default_root_dir=str(tmp_path / "run"), precision="16-mixed")
+    torch.manual_seed(0)
+    module, trainer = build_from_config(cfg)
+    with torch.no_grad():
+        for n, p in module.diffusion.named_parameters():
+            if any(z in n for z in ("ssg1.", "ssg2.", "proj_out.", "u_mod.")):
+                p.normal_(0, 0.02)
+    hist = trainer.fit(module, LatentDataModule(**cfg["data"]))
+    eng = module.diffusion.engine
+    assert module.diffusion.attn_dtype == torch.float16 and eng.attn_f16 and eng.fused_attn_bwd()
+    train = [h for h in hist if "train/loss" in h]
+    assert len(train) == 2 and all(torch.isfinite(torch.tensor(h["train/loss"])) for h in train)
+    assert any("val/loss" in h for h in hist)

@@ -882,3 +882,18 @@ def test_rope_table_long_positions(dev):
     got = out.cpu()[pos]
     assert rel_l2(got[:, : H * D], want) < 2e-6 and rel_l2(got[:, H * D:], want) < 2e-6
     assert float((got[:, : H * D] - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("M,blk,valid,K", [(300, 24, 17, 40), (700, 136, 130, 264)])
+def test_gemm_tn_blocks_drops_the_padding(dev, M, blk, valid, K):
+    """od_gemm_tn_blocks: G's columns in blocks of `blk` with `valid` live ones (the packed SwiGLU projection, 1365 of 1408 twice) — one launch over
+    the padded width must equal the two launches on the halves it replaces, rows compacted, padding columns (non-zero here) dropped, bias included."""
+    g = torch.Generator().manual_seed(77)
+    for dtype in DTYPES:
+        G, A = mk((M, 2 * blk), g, dev, dtype), mk((M, K), g, dev, dtype)
+        dW, db = torch.zeros(2 * valid, K, device=dev), torch.zeros(2 * valid, device=dev)
+        ops.gemm_tn(G, A, dW, n_cols=2 * blk, k_cols=K, dbias=db, n_block=blk, n_valid=valid)
+        Gf, Af = G.float().cpu(), A.float().cpu()
+        ref = torch.cat([Gf[:, :valid].t() @ Af, Gf[:, blk:blk + valid].t() @ Af])
+        refb = torch.cat([Gf[:, :valid].sum(0), Gf[:, blk:blk + valid].sum(0)])
+        assert rel_l2(dW, ref) < TOL[dtype] and rel_l2(db, refb) < TOL[dtype]
