@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
                                                                  float* __restrict__ lse, int B, int H, int L, float scale) {
     using St = Stage<bf16_t, 64>;
     constexpr int HD = 64, QB = NW * NQB * 32, STAGE = 2 * St::BYTES;
-    static_assert(NW == 4, "the K/V tiles are streamed as 2 + 2 one-KiB pieces per wave");
+    static_assert(NW == 4 || NW == 8, "the K/V tiles are streamed as 2 + 2 (four waves) or 1 + 1 (eight waves) one-KiB pieces per wave");
     OD_DYN_SMEM(smem);   // 2 stages x (K row-major, V row-major), 16-byte slots XOR-swizzled by row
     const int nqt = (L + QB - 1) / QB;
     int qt, bh;
@@ -522,14 +522,15 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
     const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
     // piece = 8 rows x 128 B; the swizzle (swz32, od_tiles.h) is applied on the SOURCE column; a wave's two pieces (w, w + 4)
     // have the same row bits 3..0, so one per-lane offset serves both
+    // (eight waves: wave w moves piece w of each tile alone; the per-lane offsets are the same expression with the piece index w)
     const int prow = lane >> 3, pslot = (lane & 7) ^ swz32(wave * 8 + prow);
     const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
     auto dma = [&](int kt, unsigned char* st) {
         const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u, sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
         od_buffer_lds16(rk, vk, sk, st + wave * 1024);
-        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
+        if (NW == 4) od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
         od_buffer_lds16(rv, vv, sv, st + St::BYTES + wave * 1024);
-        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + St::BYTES + (wave + 4) * 1024);
+        if (NW == 4) od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + St::BYTES + (wave + 4) * 1024);
     };
 
     // Q^T fragments (B operand): column = query, k = 16 s + 8 hi + j
@@ -1078,8 +1079,11 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
         OD_CHECK_LAUNCH();
         return 0;
     } else {
+#ifndef OD_FWD32_NW
+#define OD_FWD32_NW 4     // waves per workgroup of the bf16 / hd 64 forward (8: one workgroup per CU, the K / V tiles staged once for 256 queries; A/B)
+#endif
     if constexpr (OD_FWD32 && std::is_same<T, bf16_t>::value && HD == 64) {
-        constexpr int NW = 4, NQB = OD_FWD32_NQB;
+        constexpr int NW = OD_FWD32_NW, NQB = OD_FWD32_NQB;
         const int grid = attn_grid((L + NW * NQB * 32 - 1) / (NW * NQB * 32), B * H);
         OD_LAUNCH_DYN((flash_fwd32_kernel<NW, NQB, PRE>), dim3(grid), dim3(64 * NW), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq,
                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L, scale);
