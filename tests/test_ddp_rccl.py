@@ -117,6 +117,10 @@ def test_bench_line_through_the_rccl_path():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["collective"]["backend"].startswith("RCCL") and d["collective"]["version"] > 0
     assert d["final_loss"] == d["final_loss"] and d["value"] > 0
+    # what the exchange moves and what it costs alone (the figures an N-rank line is sanity-checked against)
+    c = d["collective"]
+    assert abs(c["bytes_per_step"] - 187.5e6) < 1e6           # the arena (46,877,504 floats: every tensor's offset rounded to 64)
+    assert c["buckets_per_step"] == 10 and c["allreduce_alone_ms"] >= 0.0
 
 
 @pytest.mark.parametrize("priority", [0, -1])
