@@ -1501,7 +1501,9 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
             static const int eff_pct = od_env_int("OD_TN_EFF_PCT", 100);      // take the SMALLEST k whose fill efficiency reaches this
             // packed order (round 3) below `xcd_min_tiles` output tiles; from there on the round-2 order (8 k splits, whole splits per XCD, several
             // block rounds), which still wins on the 24-tile qkv shape (777 vs 750 TF/s).  OD_TN_PACK=0 / 2: never / always packed (A/B).
-            static const int pack_mode = od_env_int("OD_TN_PACK", 1);
+            // Round 5: with the 4-wave kernel the packed order wins on every shape of the step — qkv (24 tiles) 803 against 811 us, the merged
+            // 22-tile proj_vg gradient 746 against 924 (the round-2 order takes 56 M-splits there: 80 M epilogue atomics) — and is the default.
+            static const int pack_mode = od_env_int("OD_TN_PACK", 2);
             int xcd_order = tiles2 >= xcd_min_tiles;
             const bool pack = pack_mode == 2 || (pack_mode == 1 && !xcd_order);
             int sp, grid_tn;

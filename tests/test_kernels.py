@@ -897,3 +897,30 @@ def test_gemm_tn_blocks_drops_the_padding(dev, M, blk, valid, K):
         ref = torch.cat([Gf[:, :valid].t() @ Af, Gf[:, blk:blk + valid].t() @ Af])
         refb = torch.cat([Gf[:, :valid].sum(0), Gf[:, blk:blk + valid].sum(0)])
         assert rel_l2(dW, ref) < TOL[dtype] and rel_l2(db, refb) < TOL[dtype]
+
+
+def test_det_api_refuses_what_it_cannot_do(dev):
+    """od_det_*: a flush outside every registered range is an error (not a silent no-op), the table holds at most 14 ranges, and clearing it
+    switches the mode off (a later kernel uses the plain float atomic again)."""
+    from osu_dreamer_amd import _lib, det
+    L = _lib.lib()
+    try:
+        det.force(True)
+        ctx = det.context(dev)
+        a, b = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        ctx.register(a)
+        with pytest.raises(_lib.HipKernelError):
+            L.od_det_flush(b.data_ptr(), b.numel(), ops._stream(b))
+        with pytest.raises(_lib.HipKernelError):
+            L.od_det_flush(a.data_ptr() + 4 * 32, 64, ops._stream(a))          # runs past the end of the range
+        keep = [torch.zeros(8, device=dev) for _ in range(13)]
+        for t in keep:
+            ctx.register(t)
+        with pytest.raises(_lib.HipKernelError):
+            ctx.register(torch.zeros(8, device=dev))                           # the 15th range
+    finally:
+        det.force(None)
+    G, A = torch.randn(70, 16).to(dev), torch.randn(70, 8).to(dev)
+    dW = torch.zeros(16, 8, device=dev)
+    ops.gemm_tn(G, A, dW)                                                      # mode off: lands in dW directly
+    assert rel_l2(dW, G.cpu().t() @ A.cpu()) < 1e-5
