@@ -309,7 +309,8 @@ class DiffusionModel(nn.Module):
             # train step with another shape in between re-plans (new workspace / packed weights), which bumps
             # `generation` and retires the graph even when the plan key comes back equal
             from .graph import CapturedLoop
-            key = (eng._plan_key, eng._packed_key, eng.generation)
+            from . import det
+            key = (eng._plan_key, eng._packed_key, eng.generation, det.enabled())     # (a captured step carries the deterministic mode's launches)
             if self._graph is None or self._graph[0] != key:
                 if self._graph is not None:
                     self._graph[1].close()
