@@ -743,10 +743,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
             // 16 j + x: the rotary partner (d, d + 32) is in the same lane, the head's sum of squares takes two shuffles.  The values are
             // rounded to the tensor type first (what the unfused path reads back); with a second output (training) C keeps them.
             T* qk = (T*)rp.qk_out;
-#ifndef OD_W4Q_X
-#define OD_W4Q_X 0        // experiments (profiles/r05b): 1 no table loads (wrong), 2 qk stored non-temporally, 4 no qk stores (wrong), 8 C stored plainly
-#endif
-            const bool c_nt = nt_store && !(OD_W4Q_X & 8);
+            const bool c_nt = nt_store;
             // rows outer, the wave's two heads inner: the (cos, sin) row of a frame is loaded once for both
             float wv[2][2][8];
             bool roped2[2], isq2[2];
@@ -763,13 +760,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                 const int gm = m0 + wm * 128 + j * 16 + x;
                 float t0[8], t1[8];                           // (cos, sin) of features 8g .. 8g+7 at this frame's position
                 if (any_roped) {
-                    if (OD_W4Q_X & 1) {
-#pragma unroll
-                        for (int e = 0; e < 8; e++) { t0[e] = (e & 1) ? 0.f : 1.f; t1[e] = t0[e]; }
-                    } else {
-                        const float* tb = rp.table + ((size_t)((gm < M ? gm : 0) % rp.L) * 32 + 8 * g) * 2;
-                        od_ld8(tb, t0); od_ld8(tb + 8, t1);
-                    }
+                    const float* tb = rp.table + ((size_t)((gm < M ? gm : 0) % rp.L) * 32 + 8 * g) * 2;
+                    od_ld8(tb, t0); od_ld8(tb + 8, t1);
                 }
 #pragma unroll
                 for (int hq = 0; hq < 2; hq++) {
@@ -812,10 +804,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                         o0[e] = y0 * cs - y1 * sn;
                         o1[e] = y1 * cs + y0 * sn;
                     }
-                    if (valid && !(OD_W4Q_X & 4)) {
+                    if (valid) {
+                        // (stored non-temporally the q, k stream takes a third off the kernel's fabric reads and nothing off the step:
+                        // profiles/r05b_qkrope_fetch.txt)
                         T* dst = qk ? qk + (size_t)gm * rp.ldqk + hc0 + 8 * g : crow;
                         if (rp.f16 && qk) { od_st8((f16_t*)dst, o0); od_st8((f16_t*)dst + 32, o1); }
-                        else if ((OD_W4Q_X & 2) && qk) { od_st8_nt(dst, o0); od_st8_nt(dst + 32, o1); }
                         else { od_st8(dst, o0); od_st8(dst + 32, o1); }
                     }
                 }
@@ -1038,9 +1031,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ G, i
     }
 }
 
-// ---- TN, large variant (bf16): 256 (n) x 256 (k) output tile, 8 waves (2 x 4) each 128 x 64, reduction
-// slabs of 64 rows staged row-major by LDS-DMA (512-byte rows, XOR swizzle at 32-byte granularity over
-// the row's 16 slot pairs), fragments by transpose reads.  Same motivation as gemm_nt_big_kernel.
+// ---- TN, large variant (bf16): 256 (n) x 256 (k) output tile, reduction slabs of 64 rows staged row-major by LDS-DMA (512-byte rows,
+// XOR swizzle at 32-byte granularity over the row's 16 slot pairs), fragments by transpose reads.  (Rounds 1-4 ran it with 8 waves of
+// 128 x 64 — gemm_tn_big_kernel, 0.76-0.89 PF/s, removed in round 5; its tile -> (n0, k0, M-split) maps live on in the kernel below.)
 __device__ __forceinline__ int tn512_off(int row, int byte) {
     return row * 512 + ((((byte >> 5)) ^ (row & 15)) << 5) + (byte & 31);
 }
@@ -1051,129 +1044,6 @@ __device__ __forceinline__ void tn512_frag(od_frag<bf16_t>& f, const unsigned ch
     f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
     f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
 }
-__global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ A, int lda,
-                                                             float* __restrict__ dW, int lddw, float* __restrict__ dbias,
-                                                             int M, int N, int K, int m_per_block, int xcd_full,
-                                                             const OdDetTable* __restrict__ det, TnRowMap rm) {
-    const int xcd_order = xcd_full & 3;
-    constexpr int STG = 65536;                 // G slab [64][256] 32 KiB + A slab [64][256] 32 KiB
-    OD_DYN_SMEM(smem);
-    float* sred = (float*)(smem + 2 * STG);    // 256 floats
-    const int tiles_n = (N + 255) / 256, tiles_k = (K + 255) / 256;
-    int tile, split;
-    if (xcd_order == 2) {
-        // "packed" order (block b runs on XCD b % 8): the (split, tile) items, split-major, are cut into 8 consecutive runs, one per XCD, so
-        // the tiles of one M-split — which stream the same G / A rows — sit on ONE XCD and share them through its L2, with the FEWEST
-        // M-splits that fill the chip (m_per_block is as long as possible: every split costs N x K fp32 atomics in the epilogue, and at
-        // 340 G atomics/s chip-wide a workgroup's 65,536 of them take ~49 us).  xcd_order = per_xcd << 2 | 2.
-        const int per_xcd = xcd_full >> 2;
-        const int gi = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-        if ((blockIdx.x >> 3) >= per_xcd) return;
-        split = gi / (tiles_n * tiles_k);
-        tile = gi % (tiles_n * tiles_k);
-    } else if (xcd_order) {
-        // XCD-aware order (block b runs on XCD b % 8): ALL output tiles of one M-split run on one XCD, side by side, so the G / A
-        // row slabs they stream are fetched from HBM once and re-read from that XCD's L2 by the other tiles of the split.  (With
-        // the tile index fastest the tiles of a split were dealt over all 8 XCDs: 3.16 GB of fetches for 1.9 GB of operands on
-        // the qkv shape, profiles/r02j_pmc_step.txt.)  Used when there are many output tiles; with few tiles the extra M-splits it
-        // needs to fill the XCDs cost more in epilogue atomics than the L2 sharing saves (profiles/r02k_ab_gemm_tn_xcd.txt).
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        split = (slot / (tiles_n * tiles_k)) * 8 + xcd;
-        tile = slot % (tiles_n * tiles_k);
-    } else {
-        tile = blockIdx.x % (tiles_n * tiles_k); split = blockIdx.x / (tiles_n * tiles_k);
-    }
-    const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
-    const int mb = split * m_per_block;
-    int me = mb + m_per_block; me = me < M ? me : M;
-    if (mb >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = od_uniform(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int x = lane & 15, g = lane >> 4;
-    const bool do_bias = dbias != nullptr && (tile % tiles_k) == 0;
-    if (tid < 256) sred[tid] = 0.f;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4)(0.f);
-    const int nslab = (me - mb + 63) / 64;
-
-    // Staging by buffer-addressed LDS-DMA issued from inline asm.  (The builtin form made hipcc put `s_waitcnt vmcnt(0)` in front of
-    // the first transpose read of every slab — the prefetch of slab st+1 was waited for before slab st was touched: DMA-only 1076,
-    // MFMA-only 1046, together 658 TF/s on the qkv shape.)  Waves 0-3 stage the G slab, 4-7 the A slab, 8 pieces of 2 rows x 512 B
-    // each; rows past this block's M range and bytes past the operand's end read as zero (the descriptor ends at row `me`); columns
-    // past N / K inside a row bring in neighbouring data that only reaches output rows / columns the epilogue drops.
-    const bool isa = wave >= 4;
-    const int ld = isa ? lda : ldg, c0 = isa ? k0 : n0, width = isa ? K : N;
-    const bf16_t* opnd = (isa ? A : G) + (size_t)mb * ld + c0;
-    // elements from `opnd` to the end of row me-1, the last row's width rounded UP to a whole 16-byte chunk (inside the row: ld % 8 == 0):
-    // the hardware range-checks per dword, and an odd width (Hf = 1365) would otherwise lose the last column of that row
-    const long avail = (long)(me - mb - 1) * ld + ((width - c0 + 7) & ~7);
-    const od_srd_t srd = od_make_srd(opnd, (unsigned)((avail > 0 ? avail : 0) * 2));
-    unsigned voff[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int r = ((wave & 3) * 8 + i) * 2 + (lane >> 5);              // row of the 64-row slab
-        const int pos = lane & 31;                                          // 16-byte position within the 512-byte LDS row
-        const int slot = ((((pos >> 1) ^ (r & 15)) << 1) | (pos & 1));
-        voff[i] = (unsigned)(r * ld * 2 + slot * 16);
-    }
-    const unsigned lds_mine = od_lds_addr(smem) + (unsigned)wave * 8192u;
-    auto dma = [&](int st, int buf) {
-        const unsigned so = (unsigned)st * 64u * (unsigned)ld * 2u, dst = lds_mine + (unsigned)buf * STG;
-#pragma unroll
-        for (int i = 0; i < 8; i++) od_buffer_lds16_at(srd, voff[i], so, dst + i * 1024u);
-    };
-    float bsum = 0.f;
-    dma(0, 0);
-    OD_WAIT_VMCNT(0);
-    __syncthreads();
-    for (int st = 0; st < nslab; st++) {
-        const int buf = st & 1;
-        if (st + 1 < nslab) dma(st + 1, buf ^ 1);
-        const unsigned char* sG = smem + buf * STG;
-        const unsigned char* sA = sG + 32768;
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            od_frag<bf16_t> fa[8], fb[4];
-#pragma unroll
-            for (int i = 0; i < 8; i++) tn512_frag(fa[i], sG, wm * 128 + i * 16, x, u, g);
-#pragma unroll
-            for (int j = 0; j < 4; j++) tn512_frag(fb[j], sA, wn * 64 + j * 16, x, u, g);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = od_mma(fa[i], fb[j], acc[i][j]);
-        }
-        if (do_bias) {
-            const int col = tid & 255, half = tid >> 8;
-#pragma unroll 8
-            for (int r = 0; r < 32; r++) bsum += od_bf2f(*(const bf16_t*)(sG + tn512_off(half * 32 + r, col * 2)));
-        }
-        OD_WAIT_VMCNT(0);
-        __syncthreads();
-    }
-    if (do_bias) atomicAdd(&sred[tid & 255], bsum);
-    long long* const dw_shadow = od_det_find(det, dW);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int n = n0 + wm * 128 + i * 16 + g * 4 + r, k = k0 + wn * 64 + j * 16 + x;
-                int no;
-                if (tn_map_row(rm, n, N, no) && k < K) od_red_add_at(dw_shadow, dW, (size_t)no * lddw + k, acc[i][j][r]);
-            }
-    if (do_bias) {
-        __syncthreads();
-        int no;
-        if (tid < 256 && tn_map_row(rm, n0 + tid, N, no)) od_red_add(det, dbias + no, sred[tid]);
-    }
-}
-
 // ---- TN, large variant, FOUR waves (round 5): gemm_nt_w4_kernel's organisation for the weight-gradient product.  One wave per SIMD, 128 (n) x 128 (k)
 // per wave with the 256 accumulators in AGPRs behind asm MFMAs, the fragments of the two 32-row halves of a 64-row slab in two register
 // sets, every transpose read / DMA piece alone between two MFMAs, two barriers per slab:
@@ -1182,8 +1052,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16_t* __res
 //   MFMA  33.. 85   the wave's 16 DMA pieces of slab st + 2 into the released stage
 //   LANDED  barrier at 88: vmcnt(16) = everything but those 16 pieces, i.e. all of slab st + 1
 //   MFMA  88..119   half 0 of slab st + 1 from the other stage -> register set 0
-// against the 8-wave kernel's read-everything / 32-MFMAs / barrier per half (0.75 transpose reads per MFMA; here 0.5).  Same tile -> (n0, k0,
-// M-split) maps, same LDS image (512-byte rows, tn512_off), same fp32-atomic epilogue (od_red_add) and bias column sums as gemm_tn_big_kernel.
+// against the retired 8-wave kernel's read-everything / 32-MFMAs / barrier per half (0.75 transpose reads per MFMA; here 0.5): +12-17 % on the
+// step's four shapes (profiles/r05_ab_records.txt).  Tile -> (n0, k0, M-split) maps (block b runs on XCD b % 8):
+//   packed (xcd_order 2): the (split, tile) items, split-major, are cut into 8 consecutive runs, one per XCD, so the tiles of one M-split — which
+//     stream the same G / A rows — sit on ONE XCD and share them through its L2, with the FEWEST M-splits that fill the chip (every split costs
+//     N x K fp32 atomics in the epilogue: at 340 G atomics/s chip-wide a workgroup's 65,536 take ~49 us).  The default on every shape.
+//   XCD-aware (1): all output tiles of one M-split side by side on one XCD, M-splits = 8 k (round 2; OD_TN_PACK=1 brings it back for >= 16 tiles).
+//   plain (0): tile index fastest.
 // every lambda of the kernel must be inlined: one that is not keeps its by-reference captures (the 256 accumulators!) in scratch memory
 #if defined(OD_EMU)
 #define TNW4_INLINE
@@ -1535,11 +1410,7 @@ int launch_tn(const T* G, int ldg, const T* A, int lda, float* dW, int lddw, flo
                 grid_tn = per_xcd * 8;
             } else
                 grid_tn = xcd_order ? ((sp + 7) / 8) * 8 * tiles2 : tiles2 * sp;
-            static const int tn_w4 = od_env_int("OD_TN_W4", 1);                  // (0: the 8-wave kernel; A/B)
-            if (tn_w4)
-                OD_LAUNCH_DYN(gemm_tn_w4_kernel, dim3(grid_tn), dim3(256), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active(), rm);
-            else
-                OD_LAUNCH_DYN(gemm_tn_big_kernel, dim3(grid_tn), dim3(512), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active(), rm);
+            OD_LAUNCH_DYN(gemm_tn_w4_kernel, dim3(grid_tn), dim3(256), (131072 + 1024), st, G, ldg, A, lda, dW, lddw, dbias, M, N, K, mpb2, xcd_order, od_det_active(), rm);
             OD_CHECK_LAUNCH();
             return 0;
         }

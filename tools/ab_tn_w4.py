@@ -22,4 +22,4 @@ for name, G, A, N, K in shapes:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     out.append(f"{name} {ms*1e3:.0f} us {2.0*M*rows*K/ms/1e9:.0f} TF/s")
-print("OD_TN_W4=" + os.environ.get("OD_TN_W4", "1") + ": " + " | ".join(out), flush=True)
+print(os.path.basename(os.environ.get("OSU_DREAMER_HIP_LIB", "libosudreamer_hip.so")) + ": " + " | ".join(out), flush=True)
