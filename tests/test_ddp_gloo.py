@@ -54,12 +54,14 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_n_rank_step_matches_averaged_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,det_mode", [(2, "0"), (8, "0"), (2, "1")])
+def test_n_rank_step_matches_averaged_oracle(tmp_path, world, det_mode, monkeypatch):
     """World sizes 2 and 8 (the size the driver's scaling run uses): every rank ends the step with identical weights / EMA / gradients,
-    equal to the oracle's step on the mean of the ranks' gradients, and every rank reduced its buckets in the same order."""
+    equal to the oracle's step on the mean of the ranks' gradients, and every rank reduced its buckets in the same order.
+    det_mode 1: the same under OD_DETERMINISTIC=1 — every arena segment's integer shadow is folded in BEFORE its bucket is handed to the exchange."""
     from kernel_backend import build_emu
     build_emu()
+    monkeypatch.setenv("OD_DETERMINISTIC", det_mode)          # the spawned ranks inherit it
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     for r in range(1, world):
