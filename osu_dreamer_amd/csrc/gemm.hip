@@ -779,13 +779,22 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                         }
                         acc[4 * hq + 2 * p][j] = bv[4 * hq + 2 * p]; acc[4 * hq + 2 * p + 1][j] = bv[4 * hq + 2 * p + 1];
                     }
+#ifndef OD_W4Q_LINE_STORES
+#define OD_W4Q_LINE_STORES 0     // 1: whole 128-byte lines here too (od_store_line_pair) — measured SLOWER in this VALU-heavy epilogue (1.33 against 1.25 ms)
+#endif
+                    const int row16 = m0 + wm * 128 + j * 16;
+                    const bool cols_ok = hc0 < N;
                     T* crow = C + (size_t)(valid ? gm : 0) * ldc + hc0 + 8 * g;
                     if (!roped && rp.f16) {                   // v as IEEE half, straight from the accumulators (no bf16 rounding in between)
-                        if (valid) { od_st8((f16_t*)crow, raw[0]); od_st8((f16_t*)crow + 32, raw[1]); }
+                        if (OD_W4Q_LINE_STORES) od_store_line_pair<f16_t, false>((f16_t*)C + hc0, (size_t)ldc, row16, x, g, M, cols_ok, raw[0], raw[1]);
+                        else if (valid) { od_st8((f16_t*)crow, raw[0]); od_st8((f16_t*)crow + 32, raw[1]); }
                         continue;
                     }
                     if (!roped || qk) {
-                        if (valid) {
+                        if (OD_W4Q_LINE_STORES) {
+                            if (c_nt) od_store_line_pair<T, true>(C + hc0, (size_t)ldc, row16, x, g, M, cols_ok, v[0], v[1]);
+                            else od_store_line_pair<T, false>(C + hc0, (size_t)ldc, row16, x, g, M, cols_ok, v[0], v[1]);
+                        } else if (valid) {
                             if (c_nt) { od_st8_nt(crow, v[0]); od_st8_nt(crow + 32, v[1]); }
                             else { od_st8(crow, v[0]); od_st8(crow + 32, v[1]); }
                         }
@@ -804,16 +813,68 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                         o0[e] = y0 * cs - y1 * sn;
                         o1[e] = y1 * cs + y0 * sn;
                     }
-                    if (valid) {
-                        // (stored non-temporally the q, k stream takes a third off the kernel's fabric reads and nothing off the step:
-                        // profiles/r05b_qkrope_fetch.txt)
+                    // (stored non-temporally the q, k stream takes a third off the kernel's fabric reads and nothing off the step:
+                    // profiles/r05b_qkrope_fetch.txt)
+                    if (OD_W4Q_LINE_STORES) {
+                        if (rp.f16 && qk) od_store_line_pair<f16_t, false>((f16_t*)qk + hc0, (size_t)rp.ldqk, row16, x, g, M, cols_ok, o0, o1);
+                        else if (qk) od_store_line_pair<T, false>(qk + hc0, (size_t)rp.ldqk, row16, x, g, M, cols_ok, o0, o1);
+                        else od_store_line_pair<T, false>(C + hc0, (size_t)ldc, row16, x, g, M, cols_ok, o0, o1);
+                    } else if (valid) {
                         T* dst = qk ? qk + (size_t)gm * rp.ldqk + hc0 + 8 * g : crow;
                         if (rp.f16 && qk) { od_st8((f16_t*)dst, o0); od_st8((f16_t*)dst + 32, o1); }
                         else { od_st8(dst, o0); od_st8(dst + 32, o1); }
                     }
                 }
             }
-        } else
+        } else {
+#ifndef OD_W4_LINE_STORES
+#define OD_W4_LINE_STORES 1     // 0: the round-3 epilogue (two 64-byte row segments per line, from two store instructions); A/B
+#endif
+#if OD_W4_LINE_STORES
+        // Whole 128-byte lines per store instruction.  A lane holds, of row 16 j + x, the columns 32 p + 8 g .. + 7 (16 bytes): the four g lanes
+        // of a row cover 64 bytes, and the second half of that line belongs to p + 1 — another instruction, written some microseconds later, so
+        // the memory system saw two partial-line writes per line (every K = 512 product wrote at the same 1.85 TB/s: profiles/r05_ab_records.txt).
+        // Here the two halves of the lane rows trade places (DPP row_shr / row_shl by 8): instruction one writes rows 0..7 of the 16, columns
+        // 64 pp .. + 63 — lanes x < 8 their own p = 2 pp piece, lanes x >= 8 the p = 2 pp + 1 piece of the lane 8 below —, instruction two rows 8..15.
+        const int xr = x & 7, xh = x >> 3;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) {
+                u32x4 ra, rb;                                  // this lane's p = 2 pp and p = 2 pp + 1 pieces, packed
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const int p = 2 * pp + h2;
+                    float v8[8];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { v8[r] = acc[2 * p][j][r]; v8[4 + r] = acc[2 * p + 1][j][r]; }
+                    acc[2 * p][j] = bv[2 * p]; acc[2 * p + 1][j] = bv[2 * p + 1];
+                    if (EPI == OD_EPI_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v8[e] = od_silu(v8[e]);
+                    }
+                    u32x4& rr = h2 ? rb : ra;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rr[i] = od_pack_bf2(v8[2 * i], v8[2 * i + 1]);
+                }
+                u32x4 lo, hi;                                  // rows 0..7 / rows 8..15 of this 16-row tile
+#pragma unroll
+                for (int i = 0; i < 4; i++) { lo[i] = od_dpp_up8(ra[i], rb[i]); hi[i] = od_dpp_down8(ra[i], rb[i]); }
+                const int gn = n0 + wn * 128 + 64 * pp + 32 * xh + 8 * g;         // lanes x >= 8 sit in the second half of the line
+                const int gm_lo = m0 + wm * 128 + j * 16 + xr, gm_hi = gm_lo + 8;
+                // rows 8..15: lanes x >= 8 write their OWN p = 2 pp piece at the line's first half, lanes x < 8 the partner's p = 2 pp + 1 piece
+                const int gn_hi = n0 + wn * 128 + 64 * pp + 32 * (1 - xh) + 8 * g;
+                if (gn < N && gm_lo < M) {
+                    T* dst = C + (size_t)gm_lo * ldc + gn;
+                    if (nt_store) od_st16_nt(dst, lo); else *(u32x4*)dst = lo;
+                }
+                if (gn_hi < N && gm_hi < M) {
+                    T* dst = C + (size_t)gm_hi * ldc + gn_hi;
+                    if (nt_store) od_st16_nt(dst, hi); else *(u32x4*)dst = hi;
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int gm = m0 + wm * 128 + j * 16 + x;
@@ -832,6 +893,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                 }
                 if (nt_store) od_st8_nt(dst, v8); else od_st8(dst, v8);
             }
+        }
+#endif
         }
         if (!more) break;
 #if !defined(OD_EMU)

@@ -182,6 +182,15 @@ template <> __device__ __forceinline__ void od_st8_nt<bf16_t>(bf16_t* p, const f
 }
 #endif
 
+// 16 packed bytes, streaming store (see od_st8_nt)
+#if defined(OD_EMU)
+__device__ __forceinline__ void od_st16_nt(void* p, u32x4 r) { *(u32x4*)p = r; }
+#else
+__device__ __forceinline__ void od_st16_nt(void* p, u32x4 r) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(p), "v"(r) : "memory");
+}
+#endif
+
 __device__ __forceinline__ float od_wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -445,6 +454,44 @@ __device__ __forceinline__ s16x4 od_lds_tr_read_at(unsigned addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)addr);
 }
 #endif
+
+// Row exchange inside the 16-lane rows of a wave (DPP row_shr:8 / row_shl:8): lanes 8..15 of each row take `src` of the lane 8 below them
+// (resp. lanes 0..7 that of the lane 8 above) and the other half keeps `old`.  The GEMM epilogues use it to turn two half-line (64-byte) row
+// segments per store instruction into whole 128-byte lines.
+#if defined(OD_EMU)
+__device__ __forceinline__ uint32_t od_dpp_up8(uint32_t old, uint32_t src) { const uint32_t t = emu::shfl(src, emu::lane_id() - 8 >= 0 ? emu::lane_id() - 8 : 0); return (emu::lane_id() & 8) ? t : old; }
+__device__ __forceinline__ uint32_t od_dpp_down8(uint32_t old, uint32_t src) { const uint32_t t = emu::shfl(src, emu::lane_id() + 8 < 64 ? emu::lane_id() + 8 : 63); return (emu::lane_id() & 8) ? old : t; }
+#else
+__device__ __forceinline__ uint32_t od_dpp_up8(uint32_t old, uint32_t src) {       // lanes x >= 8: src[lane - 8]
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x118 /* row_shr:8 */, 0xF, 0xC, false);
+}
+__device__ __forceinline__ uint32_t od_dpp_down8(uint32_t old, uint32_t src) {     // lanes x < 8: src[lane + 8]
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x108 /* row_shl:8 */, 0xF, 0x3, false);
+}
+#endif
+
+// Two 16-byte pieces per lane — columns c0 + 8 g .. + 7 (a) and c0 + 32 + 8 g .. + 7 (b) of row row16 + x, the layout the GEMM epilogues hold
+// — stored as WHOLE 128-byte lines: the two halves of the 16-lane rows trade pieces (DPP), instruction one writes rows 0..7 of the 16,
+// instruction two rows 8..15, each lane row covering columns c0 .. c0 + 63.  Every lane must call it (the exchange is wave-wide); `cols_ok` and
+// the row bounds only guard the stores.  TT = bf16_t or f16_t; NT: streaming stores.
+template <class TT, bool NT>
+__device__ __forceinline__ void od_store_line_pair(TT* base, size_t ld, int row16, int x, int g, int M, bool cols_ok, const float (&a)[8], const float (&b)[8]) {
+    u32x4 ra, rb, lo, hi;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ra[i] = od_pack2<TT>(a[2 * i], a[2 * i + 1]); rb[i] = od_pack2<TT>(b[2 * i], b[2 * i + 1]); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { lo[i] = od_dpp_up8(ra[i], rb[i]); hi[i] = od_dpp_down8(ra[i], rb[i]); }
+    const int xr = x & 7, xh = x >> 3;
+    const int row_lo = row16 + xr, row_hi = row_lo + 8;
+    if (cols_ok && row_lo < M) {
+        TT* dst = base + (size_t)row_lo * ld + 32 * xh + 8 * g;
+        if (NT) od_st16_nt(dst, lo); else *(u32x4*)dst = lo;
+    }
+    if (cols_ok && row_hi < M) {
+        TT* dst = base + (size_t)row_hi * ld + 32 * (1 - xh) + 8 * g;
+        if (NT) od_st16_nt(dst, hi); else *(u32x4*)dst = hi;
+    }
+}
 
 // 8 bf16 from a raw LDS byte address -> 8 floats
 #if defined(OD_EMU)
