@@ -589,7 +589,7 @@ def test_flash_attn_bwd_fused(dev, B, H, L, pre):
 
 
 @pytest.mark.parametrize("pre", [False, True])
-@pytest.mark.parametrize("B,H,L", [(2, 2, 75), (1, 3, 200), (1, 9, 450), (2, 1, 385)])
+@pytest.mark.parametrize("B,H,L", [(2, 2, 75), (1, 9, 450)])
 def test_flash_attn_f16_operands(dev, B, H, L, pre):
     """"Attention in fp16" (BASELINE configs[4]): q, k, v as IEEE half, P / dS / the staged dO half inside the kernels (v_mfma_f32_*_f16),
     o, dO, dq, dk, dv bf16 — od_flash_attn_fwd and od_flash_attn_bwd_fused with OD_F16 against dense fp32 autograd on the SAME (half-rounded)
