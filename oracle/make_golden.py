@@ -490,10 +490,10 @@ def gen_train_f16(out_dir, name, d: O.Dims, B, L, seed, store_full):
 
 
 def gen_round5(out_dir):
-    # head_dim 64 (the half-operand attention core exists for it only): a small two-head model with every gradient stored, and the
-    # full-width model at depth 2 (sub-sampled gradients + norms)
+    # head_dim 64 (the half-operand attention core exists for it only): a small two-head model and the full-width model at depth 2
+    # (per tensor: the gradient's norm and a 64-element sub-sample, for the fp32, bf16-autocast and fp16-autocast runs)
     gen_train_f16(out_dir, "train_f16_small_hd64_b2_l230", O.Dims(global_cond_dim=64, backbone_dim=128, n_heads=2, head_dim=64, depth=2, expand=2,
-                                                                  radius=1, u_head_dim=16), B=2, L=230, seed=1500, store_full=True)
+                                                                  radius=1, u_head_dim=16), B=2, L=230, seed=1500, store_full=False)
     gen_train_f16(out_dir, "train_f16_full_d2_b2_l96", O.Dims(depth=2), B=2, L=96, seed=1600, store_full=False)
 
 
