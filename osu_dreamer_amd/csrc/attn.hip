@@ -573,39 +573,37 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
         constexpr bool FIRST = decltype(first_t)::value;
         if (kt + 1 < nkt) dma(kt + 1, st_next);
 
-        f32x16_t sa[NQB][2];
-        auto scores = [&]() {       // S^T blocks (rows = keys); the accumulators start at -reference
-            s16x8 fk[2][4];
+        // One query block at a time between the K fragments (read once per tile, shared by the wave's query blocks) and the P fragments
+        // (kept for all of them: every V fragment is read once and applied to each): only one block's 32 score registers are live.
+        s16x8 fk[2][4];
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++)
+        for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) fk[kb][s4] = *(const s16x8*)(st + offK[s4] + kb * 4096);
+            for (int s4 = 0; s4 < 4; s4++) fk[kb][s4] = *(const s16x8*)(st + offK[s4] + kb * 4096);
+        s16x8 fp[NQB][2][2];
+#pragma unroll
+        for (int qi = 0; qi < NQB; qi++) {
+            f32x16_t sa[2];
+            // S^T blocks (rows = keys); the accumulators start at -reference
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
+                sa[kb] = od_mma32<TA>(fk[kb][0], fq[qi][0], minit[qi]);
 #pragma unroll
-                for (int qi = 0; qi < NQB; qi++) {
-                    sa[qi][kb] = od_mma32<TA>(fk[kb][0], fq[qi][0], minit[qi]);
+                for (int s4 = 1; s4 < 4; s4++) sa[kb] = od_mma32<TA>(fk[kb][s4], fq[qi][s4], sa[kb]);
+                if constexpr (!PRE) sa[kb] = sa[kb] * c + minit[qi] * (1.f - c);    // (q.k) c - reference
+                if constexpr (MASKED) {    // ragged last tile only: keys >= L
 #pragma unroll
-                    for (int s4 = 1; s4 < 4; s4++) sa[qi][kb] = od_mma32<TA>(fk[kb][s4], fq[qi][s4], sa[qi][kb]);
-                    if constexpr (!PRE) sa[qi][kb] = sa[qi][kb] * c + minit[qi] * (1.f - c);    // (q.k) c - reference
-                    if constexpr (MASKED) {    // ragged last tile only: keys >= L
-#pragma unroll
-                        for (int r = 0; r < 16; r++)
-                            if (kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) sa[qi][kb][r] = NEG_BIG;
-                    }
+                    for (int r = 0; r < 16; r++)
+                        if (kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= L) sa[kb][r] = NEG_BIG;
                 }
             }
-        };
-        scores();
-        // exact path: move the reference to the row maximum (always on the first tile; otherwise only when the guard trips)
-        auto exact = [&]() {
-#pragma unroll
-            for (int qi = 0; qi < NQB; qi++) {
+            // exact path: move the reference to the row maximum (always on the first tile; otherwise only when the guard trips)
+            auto exact = [&]() {
                 float m = NEG_BIG;
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) m = fmaxf(m, sa[qi][kb][r]);
+                    for (int r = 0; r < 16; r++) m = fmaxf(m, sa[kb][r]);
                 m = fmaxf(m, __shfl_xor(m, 32));               // the two half-waves hold complementary keys of the same query
                 const float d = FIRST ? m : fmaxf(m, 0.f);     // scores are relative to the current reference
                 if constexpr (!FIRST) {
@@ -616,14 +614,10 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
                 mref[qi] += d;                                 // log2 units
                 minit[qi] = (f32x16_t)(-mref[qi]);
 #pragma unroll
-                for (int kb = 0; kb < 2; kb++) sa[qi][kb] -= d;
-            }
-        };
-        s16x8 fp[NQB][2][2];
-        float ps[NQB];
-        auto probs = [&]() {
-#pragma unroll
-            for (int qi = 0; qi < NQB; qi++) {
+                for (int kb = 0; kb < 2; kb++) sa[kb] -= d;
+            };
+            float ps;
+            auto probs = [&]() {
                 float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++)
@@ -632,25 +626,21 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
                         u32x4 w;
 #pragma unroll
                         for (int jj = 0; jj < 4; jj++) {
-                            const float p0 = od_exp2(sa[qi][kb][8 * sl + 2 * jj]), p1 = od_exp2(sa[qi][kb][8 * sl + 2 * jj + 1]);
+                            const float p0 = od_exp2(sa[kb][8 * sl + 2 * jj]), p1 = od_exp2(sa[kb][8 * sl + 2 * jj + 1]);
                             acc0 += p0; acc1 += p1;
                             w[jj] = od_pack2<TA>(p0, p1);
                         }
                         fp[qi][kb][sl] = __builtin_bit_cast(s16x8, w);
                     }
-                ps[qi] = acc0 + acc1;
+                ps = acc0 + acc1;
+            };
+            if constexpr (FIRST) { exact(); probs(); }
+            else {
+                probs();
+                if (__any(!(ps < OD_FWD32_GUARD))) { exact(); probs(); }       // wave-uniform, rare
             }
-        };
-        if constexpr (FIRST) { exact(); probs(); }
-        else {
-            probs();
-            bool bad = false;
-#pragma unroll
-            for (int qi = 0; qi < NQB; qi++) bad |= !(ps[qi] < OD_FWD32_GUARD);
-            if (__any(bad)) { exact(); probs(); }       // wave-uniform, rare
+            lrun[qi] += ps;
         }
-#pragma unroll
-        for (int qi = 0; qi < NQB; qi++) lrun[qi] += ps[qi];
         // O^T += V^T P^T : A = V^T fragment (rows = features of block db), two transpose reads per 16-key slab
 #pragma unroll
         for (int db = 0; db < 2; db++)
