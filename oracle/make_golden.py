@@ -95,7 +95,7 @@ def _ref_model(d: O.Dims, P: O.Params):
     return m
 
 
-def _ref_trainer(d: O.Dims, P: O.Params, val_batches=2):
+def _ref_trainer(d: O.Dims, P: O.Params, val_batches=2, warmup_steps=1000, decay_start=30000):
     from osu_dreamer.models.diffusion.train import DiffusionTrainer
     from osu_dreamer.models.diffusion.model import DiffusionModelArgs
     from osu_dreamer.models.diffusion.backbone import BackboneArgs
@@ -107,7 +107,7 @@ def _ref_trainer(d: O.Dims, P: O.Params, val_batches=2):
         u_head_dim=d.u_head_dim)
     tr = DiffusionTrainer(
         val_batches=val_batches, opt_args=dict(lr=3e-4, weight_decay=0.01),
-        schedule_args=LRScheduleArgs(warmup_init=.3, warmup_steps=1000, decay_start=30000),
+        schedule_args=LRScheduleArgs(warmup_init=.3, warmup_steps=warmup_steps, decay_start=decay_start),
         osl_weight=1., del_weight=30., emb_dim=d.emb_dim, a_dim=d.a_dim, style_dim=d.style_dim,
         diffusion_args=args)
     torch.set_float32_matmul_precision("highest")   # train.py:53 flips it globally
@@ -497,6 +497,71 @@ def gen_round5(out_dir):
     gen_train_f16(out_dir, "train_f16_full_d2_b2_l96", O.Dims(depth=2), B=2, L=96, seed=1600, store_full=False)
 
 
+TRAJ_WARMUP, TRAJ_DECAY = 12, 24          # the trajectory fixtures' schedule: warm-up, plateau and the start of the decay all fall inside 40 steps
+
+
+def gen_trajectory(out_dir, name, d: O.Dims, B, L, seed, steps=40):
+    """A TRAINING TRAJECTORY of the reference (models/diffusion/train.py:69-126): `steps` consecutive optimizer steps of DiffusionTrainer —
+    forward + loss (fresh batch, t and x0 per step, regenerated from seed + 10 i on both sides), backward, clip 1.0 (model.yml:39),
+    AdamW (train.py:110-121: bias correction, weight decay), the LR schedule (common/lr_schedule.py:10-21; warm-up 12 steps, decay from
+    step 24 so that all three branches are walked) and the EMA copy-then-lerp (train.py:125-126) — once in fp32 and once with the forward
+    under torch.autocast(bfloat16) (`precision: bf16-mixed`, model.yml:12).  Stored: the loss terms and the learning rate of every step,
+    and of the final weights and EMA weights each tensor's norm and a 64-element sub-sample, per run."""
+    import osu_dreamer.models.diffusion.train as train_mod
+    P = O.init_params(d, seed=seed)
+    fx = {"dims": np.array(list(d.to_dict().values())), "B": B, "L": L, "seed": seed, "steps": steps,
+          "warmup_steps": TRAJ_WARMUP, "decay_start": TRAJ_DECAY}
+    t_used = []
+    for tag, mk_ctx in (("f32", lambda: torch.autocast("cpu", enabled=False)), ("bf16", lambda: torch.autocast("cpu", dtype=torch.bfloat16))):
+        tr = _ref_trainer(d, P, warmup_steps=TRAJ_WARMUP, decay_start=TRAJ_DECAY)
+        cfg = tr.configure_optimizers()
+        opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+        losses, logs_all, lrs, gnorms = [], {}, [], []
+        for i in range(steps):
+            data = O.synthetic_batch(d, B, L, seed=seed + 1 + 10 * i)
+            u01 = torch.special.ndtr(torch.logit(data["t"].double())).float()
+            if tag == "f32":
+                u_eff = (torch.zeros(B) + u01 * B) / B
+                t_used.append(torch.special.ndtri(u_eff.clamp(1e-6, 1 - 1e-6)).sigmoid())
+            lrs.append(opt.param_groups[0]["lr"])          # the rate this step's update uses
+            with _FixedNoise(train_mod, u01, data["x0"]):
+                opt.zero_grad()
+                with mk_ctx():
+                    loss, logs = tr(tr.diffusion, data["h"], data["z"], data["s"], torch.zeros(B, 5))
+            loss.backward()
+            gnorms.append(float(torch.nn.utils.clip_grad_norm_(tr.parameters(), 1.0)))
+            opt.step()
+            sched.step()
+            tr.on_train_batch_end()
+            losses.append(float(loss.detach()))
+            for k, v in logs.items():
+                logs_all.setdefault(k, []).append(float(v))
+        fx[f"{tag}.loss"] = np.array(losses, dtype=np.float64)
+        fx[f"{tag}.grad_norm"] = np.array(gnorms, dtype=np.float64)
+        fx[f"{tag}.lr"] = np.array(lrs, dtype=np.float64)
+        for k, v in logs_all.items():
+            fx[f"{tag}.log_{k}"] = np.array(v, dtype=np.float64)
+        fx[f"{tag}.n_averaged"] = tr.diffusion_ema.n_averaged
+        pw = dict(tr.diffusion.named_parameters())
+        ew = dict(tr.diffusion_ema.module.named_parameters())
+        for k in pw:
+            for pre, w in (("p", pw[k]), ("ema", ew[k])):
+                w = w.detach().float()
+                fx[f"{tag}.{pre}norm." + k] = w.norm()
+                fx[f"{tag}.{pre}sub." + k] = w.flatten()[::max(1, w.numel() // 64)][:64]
+            fx[f"{tag}.dnorm." + k] = (pw[k].detach() - P[k]).norm()       # how far the tensor moved: the scale of the comparison
+    fx["t_used"] = torch.stack(t_used)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **np_dict(**fx))
+    print(name, "loss f32", fx["f32.loss"][[0, steps // 2, -1]], "bf16", fx["bf16.loss"][[0, steps // 2, -1]], "lr", fx["f32.lr"][[0, TRAJ_WARMUP, -1]])
+
+
+def gen_round6(out_dir):
+    gen_trajectory(out_dir, "traj40_tiny_b3_l40", O.TINY, B=3, L=40, seed=1700)
+    # head_dim 64, two heads: the shape class whose bf16 step runs the MFMA attention kernels the bench runs
+    gen_trajectory(out_dir, "traj40_small_hd64_b2_l130", O.Dims(global_cond_dim=64, backbone_dim=128, n_heads=2, head_dim=64, depth=2, expand=2,
+                                                                radius=1, u_head_dim=16), B=2, L=130, seed=1800)
+
+
 def gen_validation(out_dir, name, d: O.Dims, val_batches, l, seed):
     """The reference's `validation_step` (train.py:128-139): one full map (1, C, l) cut into `val_batches` segments,
     loss under no_grad with the EMA weights.  The EMA copy is given DIFFERENT weights from the live model so that a
@@ -655,6 +720,9 @@ def main():
     if os.environ.get("GOLDEN_ONLY") == "round5":
         gen_round5(out_dir)
         return
+    if os.environ.get("GOLDEN_ONLY") == "round6":
+        gen_round6(out_dir)
+        return
     gen_lr(out_dir)
     gen_ops(out_dir)
     from oracle import style_oracle as SO
@@ -689,6 +757,8 @@ def main():
               num_steps=4)
     gen_round2(out_dir)
     gen_round3(out_dir)
+    gen_round5(out_dir)
+    gen_round6(out_dir)
 
 
 if __name__ == "__main__":

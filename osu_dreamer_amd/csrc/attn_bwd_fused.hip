@@ -113,6 +113,7 @@ __device__ __forceinline__ void fb_flag_store(int* p, int v) { *p = v; }
 struct fb_rsrc_t { const unsigned char* base; };
 __device__ __forceinline__ fb_rsrc_t fb_make_rsrc(const float* base, unsigned) { return fb_rsrc_t{(const unsigned char*)base}; }
 __device__ __forceinline__ f32x4 fb_ld_l2(fb_rsrc_t r, unsigned voff, unsigned soff) { return *(const f32x4*)(r.base + voff + soff); }
+__device__ __forceinline__ void fb_st_run(float* p, f32x4 t) { *(f32x4*)p = t; }
 __device__ __forceinline__ void fb_sleep() {}
 // the emulator runs the workgroups one after the other: a predecessor's write is either there or will never come — every poll costs one "tick"
 __device__ __forceinline__ unsigned long long fb_now(unsigned polls) { return polls; }
@@ -140,6 +141,22 @@ __device__ __forceinline__ fb_rsrc_t fb_make_rsrc(const float* base, unsigned by
 }
 __device__ __forceinline__ f32x4 fb_ld_l2(fb_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, FB_LD_AUX));
+}
+// a running-tile store.  FB_ST_POLICY: 0 = plain (the line stays in the XCD's L2: the successor's sc1 load finds it there), 1 = nt, 2 = sc1,
+// 3 = sc0 sc1 (write-through forms: the line is dropped / bypasses) — round-6 A/B, profiles/r06a_chain_policy.txt
+#ifndef FB_ST_POLICY
+#define FB_ST_POLICY 0
+#endif
+__device__ __forceinline__ void fb_st_run(float* p, f32x4 t) {
+#if FB_ST_POLICY == 0
+    *(f32x4*)p = t;
+#elif FB_ST_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(t) : "memory");
+#elif FB_ST_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(t) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(t) : "memory");
+#endif
 }
 __device__ __forceinline__ void fb_sleep() { __builtin_amdgcn_s_sleep(4); }
 // the constant 100 MHz counter (s_memrealtime): the budget of a chain wait is wall time, whatever the shader clock does
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                         f32x4 t;
 #pragma unroll
                         for (int r = 0; r < 4; r++) t[r] = fb_u2f((fb_f2u(a[G][r]) & ~7u) | tag_of(id_mine, r));
-                        *(f32x4*)(run_st + (size_t)tau * tile_f + G * 256) = t;
+                        fb_st_run(run_st + (size_t)tau * tile_f + G * 256, t);
                     }
                 } else {
 #pragma unroll
@@ -607,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
 #pragma unroll
                     for (int r = 0; r < 4; r++) t[r] = fb_u2f(tag_of(id_mine, r));
 #pragma unroll
-                    for (int G = 0; G < 4; G++) *(f32x4*)(run_st + (size_t)tau * tile_f + G * 256) = t;
+                    for (int G = 0; G < 4; G++) fb_st_run(run_st + (size_t)tau * tile_f + G * 256, t);
                 }
             };
             auto commit_dyn = [&](int tau) FB_INLINE {                             // the share of tile tau sits in ring slot tau & 3 (a wave-uniform switch)

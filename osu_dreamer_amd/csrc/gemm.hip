@@ -24,6 +24,9 @@ namespace {
 #ifndef OD_GEMM_BIG_MIN_M
 #define OD_GEMM_BIG_MIN_M 32768   // rows from which the 256x256 kernels are used
 #endif
+#ifndef OD_NT_BIG_MIN_TILES
+#define OD_NT_BIG_MIN_TILES 0     // (see launch_nt)
+#endif
 
 constexpr int BM = 128, BN = 128;
 constexpr int STAGE_BYTES = 32768;  // A 16 KiB + B 16 KiB
@@ -562,6 +565,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const T* __restrict
 #ifndef OD_W4_X
 #define OD_W4_X 0          // timing experiments only (wrong results): 2 no loop fragment reads, 4 no loop barriers, 8 no loop waits, 16 no fetch
 #endif
+#ifndef OD_W4_STAGGER
+#define OD_W4_STAGGER 0
+#endif
 template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ C, int ldc,
@@ -588,6 +594,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
     const int wm = wave >> 1, wn = wave & 1;
     const int x = lane & 15, g = lane >> 4;
     const int nk = K / 64;
+#if OD_W4_STAGGER && !defined(OD_EMU)
+    // A/B (round 6): every second workgroup of an XCD starts OD_W4_STAGGER x ~4 us late, so that the store bursts of the epilogues (all
+    // workgroups walk tiles of equal length) do not fall on top of each other
+    if ((blockIdx.x >> 3) & 1) {
+#pragma unroll 1
+        for (int i = 0; i < OD_W4_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     // The accumulators START at the bias: lane (x, g) holds, for output row m0 + wm*128 + 16 j + x, the columns n0 + wn*128 + 32 p + 8 g .. + 7
     // (acc[2p][j][0..3], acc[2p+1][j][0..3]) — the same eight bias values for every j.  (A bias load in the epilogue would sit behind the
@@ -1372,7 +1386,14 @@ int launch_nt(const T* A, int lda, const T* W, int ldw, const float* bias, T* C,
     // q/k norm + RoPE in the large-M kernel's epilogue: bf16, head_dim 64 (a wave's 64 columns are one head), whole 256-column tiles
     const bool big_rope = epi == OD_EPI_QKROPE && std::is_same<T, bf16_t>::value && rp.hd == 64 && rp.n_rope % 64 == 0 && N % 64 == 0 &&
                           (!rp.qk_out || rp.ldqk % 8 == 0);
-    if ((epi != OD_EPI_QKROPE || big_rope) && dma && M >= OD_GEMM_BIG_MIN_M && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
+    // Below OD_GEMM_BIG_MIN_M rows (the sampler: M = 4460) a product whose 256 x 256 tiles fill most of the chip in ONE round — qkv (N = 3072:
+    // 216 tiles) and proj_vg (N = 2816: 198) — still takes the 4-wave persistent kernel: its tile time beats the 128-row kernel's three rounds
+    // (round 6: profiles/r06b_ab_sampler_big_tiles.txt).  OD_NT_BIG_MIN_TILES: the fewest tiles for that (0 = never).
+    static const int big_min_tiles = od_env_int("OD_NT_BIG_MIN_TILES", OD_NT_BIG_MIN_TILES);
+    const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const bool big_by_tiles = std::is_same<T, bf16_t>::value && big_min_tiles > 0 && M >= 1024 && tiles256 >= big_min_tiles && tiles256 <= od_num_cus() &&
+                              !accumulate && K % 128 == 0;
+    if ((epi != OD_EPI_QKROPE || big_rope) && dma && (M >= OD_GEMM_BIG_MIN_M || big_by_tiles) && N % 8 == 0 && ldc % 8 == 0 && N >= 256) {
         const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256;
         const int grid2 = ((tm2 + 7) / 8) * 8 * tn2;
         // Wide outputs are written with non-temporal stores: the 128 KiB tile bursts of 256 CUs (32 MiB, the size of all L2s) otherwise

@@ -227,6 +227,22 @@ class DiffusionModel(nn.Module):
             g.zero_()
         return g
 
+    def adopt_grads(self):
+        """Before an optimizer step: make the arena's gradient buffer hold what every parameter's `.grad` says.  Normally they are the same
+        memory (attach_grads) and nothing is copied.  A wrapper that RE-POINTS `.grad` after backward — torch DDP with
+        `gradient_as_bucket_view=True` leaves each `.grad` a view of its all-reduced bucket — is honoured by copying those gradients into the
+        arena (the fused optimizer reads the arena; re-attaching alone would have zeroed it and stepped on nothing)."""
+        g = self.arena.ensure_grad()
+        for name, p in self.named_parameters():
+            gv = self.arena.grad_view(name)
+            if p.grad is None:
+                gv.zero_()
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad.reshape(gv.shape))
+                p.grad = gv
+        return g
+
     @property
     def engine(self) -> DenoiserEngine:
         if self._engine is None:

@@ -49,7 +49,7 @@ class FusedAdamWEMA(torch.optim.Optimizer):
         reducer = getattr(model, "_reducer", None)
         if reducer is not None:
             reducer.wait()                       # gradient all-reduce must have landed
-        g = model.attach_grads()
+        g = model.adopt_grads()                  # = the arena's gradient buffer (foreign .grad tensors, e.g. DDP bucket views, are copied in)
         grp = self.param_groups[0]
         self.step_count += 1
         clip = float(self.max_grad_norm) if self.max_grad_norm else 0.0

@@ -266,3 +266,82 @@ def test_dead_rank_ends_the_job_nonzero(tmp_path):
     assert dt < 300, f"the surviving rank took {dt:.0f} s to give up"
     assert (tmp_path / "alive0").exists() and (tmp_path / "alive1").exists(), "both ranks were training before the failure"
     assert not (tmp_path / "finished0").exists() and not (tmp_path / "finished1").exists()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# torch's own DistributedDataParallel around DiffusionTrainer (what Lightning's `devices: N` / strategy "ddp" builds around the
+# reference's module, model.yml:11).  The denoiser's autograd node returns None for every parameter and writes
+# the gradient arena directly (train.py, model.py: `p.grad` aliases the arena), which is the shape that usually breaks DDP's reducer:
+# its post-accumulate hooks must still fire and must read `param.grad`.  Checked: after backward through the wrapper every rank holds
+# the MEAN of the ranks' local gradients (bit for bit against a gloo all-reduce of the local arenas), for two iterations (the second
+# runs on the reducer's rebuilt buckets), and with gradient_as_bucket_view=True — where DDP re-points `.grad` into its buckets — the
+# arena still holds the averaged gradient that FusedAdamWEMA reads.
+def _torch_ddp_worker(rank, world, port, out_dir, bucket_view):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from oracle import denoiser_oracle as O
+    from osu_dreamer_amd import _lib
+    from kernel_backend import EMU_SO
+    from test_model_parity import make_trainer
+    _lib.use_library(EMU_SO)
+    d = O.TINY
+    P = O.init_params(d, seed=70)
+
+    def local_grads(it):
+        """the gradient this rank's batch gives WITHOUT the wrapper (same weights): what DDP has to average"""
+        tr0 = make_trainer(d, P, torch.device("cpu"))
+        data = O.synthetic_batch(d, 2, 24, seed=80 + 10 * it + rank)
+        loss, _ = tr0(tr0.diffusion, data["h"], data["z"], data["s"], None, t=data["t"], x0=data["x0"])
+        loss.backward()
+        return tr0.diffusion.arena.grad.clone(), data
+
+    tr = make_trainer(d, P, torch.device("cpu"))
+    for p in tr.diffusion_ema.parameters():
+        p.requires_grad_(False)
+    ddp = DDP(tr, gradient_as_bucket_view=bucket_view)
+    out = {"max_diff": [], "arena_is_grad": []}
+    for it in range(2):
+        g_local, data = local_grads(it)
+        want = g_local.clone()
+        dist.all_reduce(want)
+        want /= world
+        if tr.diffusion.arena.grad is not None:
+            tr.diffusion.arena.grad.zero_()
+        loss, _ = ddp(tr.diffusion, data["h"], data["z"], data["s"], None, t=data["t"], x0=data["x0"])
+        loss.backward()
+        model = tr.diffusion
+        # what the optimizer reads: the arena's gradient buffer; and what every parameter's .grad says
+        got_arena = model.arena.grad
+        per_param = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for _, p in model.named_parameters()])
+        want_params = torch.cat([model.arena.view(k, want).reshape(-1) for k, _ in model.named_parameters()])
+        out["max_diff"].append((float((got_arena - want).abs().max()), float((per_param - want_params).abs().max())))
+        out["arena_is_grad"].append(all(p.grad is not None and p.grad.data_ptr() == model.arena.view(k, model.arena.grad).data_ptr()
+                                        for k, p in model.named_parameters()))
+        # what FusedAdamWEMA.step does first: adopt whatever .grad the wrapper left (a no-op when .grad still aliases the arena)
+        out.setdefault("adopted_diff", []).append(float((model.adopt_grads() - want).abs().max()))
+    torch.save(out, os.path.join(out_dir, f"ddp{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_view", [False, True])
+def test_torch_ddp_wrapper_averages_the_arena_gradients(tmp_path, bucket_view):
+    from kernel_backend import build_emu
+    build_emu()
+    mp.spawn(_torch_ddp_worker, args=(2, _free_port(), str(tmp_path), bucket_view), nprocs=2, join=True)
+    for r in range(2):
+        o = torch.load(tmp_path / f"ddp{r}.pt")
+        for it, (d_arena, d_params) in enumerate(o["max_diff"]):
+            assert d_params == 0.0, (r, it, d_params)       # every p.grad is the mean of the ranks' local gradients, bit for bit
+            if not bucket_view:
+                assert d_arena == 0.0, (r, it, d_arena)     # ... and it still lives in the arena FusedAdamWEMA reads
+        if not bucket_view:
+            assert all(o["arena_is_grad"]), "DDP without bucket views must leave p.grad aliasing the arena"
+        else:
+            # gradient_as_bucket_view=True re-points p.grad into DDP's buckets (the arena keeps the LOCAL gradient): FusedAdamWEMA.step adopts
+            # the averaged .grad into the arena before it reads it (DiffusionModel.adopt_grads)
+            assert not any(o["arena_is_grad"])
+        assert all(a == 0.0 for a in o["adopted_diff"]), o["adopted_diff"]

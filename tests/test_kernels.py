@@ -514,7 +514,7 @@ def test_flash_attention(dev, dtype, B, H, L, hd):
     s = heads(qr) @ heads(kr).transpose(-1, -2) * scale
     ref = (torch.softmax(s, -1) @ heads(vr)).permute(0, 2, 1, 3).reshape(M, dh)
     assert rel_l2(o.float(), ref) < TOL[dtype]
-    assert rel_l2(lse, torch.logsumexp(s, -1)) < 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert rel_l2(lse, torch.logsumexp(s, -1)) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
     do = mk((M, dh), g, dev, dtype)
     ref.backward(do.float().cpu())
     dq, dk, dv = (torch.zeros(M, dh, dtype=dtype, device=dev) for _ in range(3))

@@ -34,8 +34,11 @@ def child():
 if os.environ.get("AB_CHILD") == "1":
     child()
 else:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ab_common import parse          # spec = lib.so | lib.so@ENV=VAL,... | @ENV=VAL (in-tree library)
     for rnd in range(2):
-        for lib in sys.argv[1:]:
-            env = dict(os.environ, AB_CHILD="1", OSU_DREAMER_HIP_LIB=os.path.abspath(lib))
+        for spec in sys.argv[1:]:
+            label, libpath, extra = parse(spec)
+            env = dict(os.environ, AB_CHILD="1", OSU_DREAMER_HIP_LIB=libpath, **extra)
             r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True, timeout=300)
-            print(f"[round {rnd}] {os.path.basename(lib):28s} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]}", flush=True)
+            print(f"[round {rnd}] {label:40s} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]}", flush=True)
