@@ -161,11 +161,12 @@ class PowerSampler:
     process (a `rocm-smi` child is an exec from a GPU-initialised process: refused under rocprofv3) and nothing that changes a GPU setting.
     Every field is None where the files are absent or unreadable."""
 
-    def __init__(self, device_index=0, period_s=0.1):
+    def __init__(self, device_index=0, period_s=0.01):
         import threading
-        self.period = period_s
+        self.period = period_s                      # 100 Hz: the power trace is integrated into joules when the board has no energy counter
         self.dir = self._hwmon_of(device_index)
         self.samples, self._stop, self._thr = [], threading.Event(), None
+        self.times, self.t_enter, self.t_exit, self.e_enter, self.e_exit = [], None, None, None, None
 
     @staticmethod
     def _hwmon_of(device_index):
@@ -206,14 +207,31 @@ class PowerSampler:
                 r = self._read()
                 if r is not None:
                     self.samples.append(r)
+                    self.times.append(time.perf_counter())
                 self._stop.wait(self.period)
+        self.e_enter = self._num("energy1_input") if self.dir is not None else None      # microjoules since boot, where the driver exposes it
+        self.t_enter = time.perf_counter()
         self._thr = threading.Thread(target=loop, daemon=True)
         self._thr.start()
         return self
 
     def __exit__(self, *exc):
+        self.t_exit = time.perf_counter()
+        self.e_exit = self._num("energy1_input") if self.dir is not None else None
         self._stop.set()
         self._thr.join(timeout=10)
+
+    def joules(self):
+        """Energy the board drew between __enter__ and __exit__: the hwmon energy counter's delta where there is one, otherwise the power trace
+        integrated over the region (trapezoid rule over the 100 Hz samples, the first / last reading held to the region's ends).  (value, source)"""
+        if self.e_enter is not None and self.e_exit is not None and self.e_exit > self.e_enter:
+            return (self.e_exit - self.e_enter) / 1e6, "hwmon energy1_input delta"
+        pts = [(t, p) for t, (p, _) in zip(self.times, self.samples) if p is not None and self.t_enter is not None and self.t_exit is not None]
+        if len(pts) < 2:
+            return None, "no power readings"
+        pts = [(self.t_enter, pts[0][1])] + [(t, p) for t, p in pts if self.t_enter < t < self.t_exit] + [(self.t_exit, pts[-1][1])]
+        e = sum(0.5 * (p0 + p1) * (t1 - t0) for (t0, p0), (t1, p1) in zip(pts, pts[1:]))
+        return e, f"integral of hwmon power1_input over the region ({len(pts) - 2} samples at {1.0 / self.period:.0f} Hz, trapezoid)"
 
     def cap_w(self):
         v = self._num("power1_cap") if self.dir is not None else None
@@ -624,6 +642,12 @@ def main():
         # what box / what throttle state this line was taken in (rank 0's GPU): board power and shader clock sampled over the timed region
         line.update({k: v for k, v in sampler.summary().items() if k in ("clk_mhz_mean", "power_w_mean", "power_cap_w")})
         line["power_sampling"] = {k: v for k, v in sampler.summary().items() if k in ("samples", "source")}
+        # energy: what the board drew over the timed region, per step and per algorithmic PFLOP (rank 0's GPU) — the quantity that sets the
+        # rate of a power-capped kernel; per kernel class: tools/energy_classes.py -> profiles/r06_energy_classes.txt
+        ej, esrc = sampler.joules()
+        line["joules_per_step"] = round(ej / args.steps, 1) if ej is not None else None
+        line["joules_per_algorithmic_pflop"] = round(ej / args.steps / (3 * f_fwd / 1e15), 2) if ej is not None else None
+        line["energy_source"] = esrc
         if ddp:
             line["collective"] = {"backend": "RCCL via od_allreduce_grads", "version": reducer.comm.version,
                                   "exchange": "od_allreduce_grads per arena segment (187.5 MB fp32 per step), overlapped with backward",

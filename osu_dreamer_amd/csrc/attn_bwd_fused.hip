@@ -54,8 +54,8 @@ constexpr int FB_SMEM = FB_KST + FB_DS + 16;
 #define FB_SPLIT 1     // how the four query waves split the dQ product of a tile (see there; 0, 2: measured alternatives, profiles/r04ae, r04al)
 #endif
 #ifndef FB_X
-#define FB_X 0        // timing experiments only (wrong dq): bit 0 = no chain traffic, bit 1 = no dQ products, bit 2 = no dS publication, bit 8 = no exp2, bit 9 = no transposed Q / dO reads after the first, bit 10 = no row-major Q / dO reads after the first, bit 3 = no running-tile loads,
-                      // bit 4 = no running-tile stores, bit 5 = tags not checked
+#define FB_X 0        // timing experiments only (wrong dq): bit 0 = no chain traffic, bit 1 = no dQ products, bit 2 = no dS publication, bit 8 = no exp2, bit 9 = no transposed Q / dO reads after the first, bit 10 = no row-major Q / dO reads after the first,
+                      // bit 3 = every running-tile load / store goes to tile 0 of its slot (the traffic never leaves the L2), bit 5 = tags not checked (nobody waits for a predecessor), bit 4 = no running-tile stores, bit 6 = no running-tile loads (both with bit 5)
 #endif
 
 // every lambda of the kernel must be inlined: one that is not keeps its by-reference captures (the accumulator rings!) in scratch memory
@@ -132,8 +132,12 @@ __device__ __forceinline__ int fb_flag_load(const int* p) { return __hip_atomic_
 __device__ __forceinline__ void fb_flag_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // 16 bytes of the running sum, L1-bypassing and COMPILER-VISIBLE (the value is used an iteration later: the compiler must know the registers
 // are pending): buffer_load_dwordx4 ... offen sc1 through a descriptor over this (batch, head)'s running tiles
+// Cache policy of the running-tile loads: any L1-bypassing form is correct (the tags reject what is not the predecessor's write).  Round 6 A/B
+// (profiles/r06b_chain_price_policy.txt, same box): sc1 (16; rounds 4-5) 21.74 ms, sc0 sc1 (17) +-0, nt (2) and sc1 nt (18) 21.18 ms = -2.6 %,
+// -5.9 ms per training step — a running tile is read ONCE by its one consumer, and the streaming hint keeps it from displacing the Q / dO
+// tiles the XCD's other 31 key blocks re-read from the L2.
 #ifndef FB_LD_AUX
-#define FB_LD_AUX 16      /* sc1 */
+#define FB_LD_AUX 2       /* nt */
 #endif
 typedef __amdgpu_buffer_rsrc_t fb_rsrc_t;
 __device__ __forceinline__ fb_rsrc_t fb_make_rsrc(const float* base, unsigned bytes) {
@@ -148,14 +152,16 @@ __device__ __forceinline__ f32x4 fb_ld_l2(fb_rsrc_t r, unsigned voff, unsigned s
 #define FB_ST_POLICY 0
 #endif
 __device__ __forceinline__ void fb_st_run(float* p, f32x4 t) {
-#if FB_ST_POLICY == 0
+#if FB_X & 16
+    asm volatile("" :: "v"(t));
+#elif FB_ST_POLICY == 0
     *(f32x4*)p = t;
 #elif FB_ST_POLICY == 1
-    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(t) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" :: "v"(p), "v"(t) : "memory");      // (s_nop: see od_st8_nt)
 #elif FB_ST_POLICY == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(t) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(t) : "memory");
 #else
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(t) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(t) : "memory");
 #endif
 }
 __device__ __forceinline__ void fb_sleep() { __builtin_amdgcn_s_sleep(4); }
@@ -212,13 +218,14 @@ __global__ __launch_bounds__(256) void fb_amax_kernel(const bf16_t* __restrict__
     for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, fb_f2u(m));
 }
-// the power of two that brings amax into (32, 64]: products with v (|v| ~ 1-10, 64 terms) and with P <= 1 then stay far below half's 65504,
-// and 2^-24 (half's smallest subnormal) is 2^-30 of the largest element.  1 for an all-zero or non-finite tensor.
+// the power of two that brings amax into (2, 4]: dP = dO V^T sums 64 products, so |dS| <= 64 * 4 * max|v| stays below half's 65504 up to
+// max|v| = 255 (round 5 aimed at (32, 64], which left room for |v| < 16 only: ADVICE r5), and 2^-24 (half's smallest subnormal) is still
+// 2^-26 of the largest element.  1 for an all-zero or non-finite tensor.
 __device__ __forceinline__ float fb_dscale_of(unsigned amax_bits) {
     const unsigned e = (amax_bits >> 23) & 0xffu;
     if (amax_bits == 0u || e == 0u || e == 0xffu) return 1.0f;
     const int ex = (int)e - 127 + ((amax_bits & 0x7fffffu) ? 1 : 0);      // ceil(log2(amax))
-    int se = 6 - ex; se = se < -100 ? -100 : se > 100 ? 100 : se;
+    int se = 2 - ex; se = se < -100 ? -100 : se > 100 ? 100 : se;
     return fb_u2f((unsigned)(se + 127) << 23);
 }
 // fb_prep_kernel + the staged copy: nl = -lse', nd = -dscale * delta, do16 = half(dscale * dout)
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256) void fb_prep_f16_kernel(const bf16_t* __restri
 
 // TA = the MFMA operand type: bf16_t, or f16_t ("attention in fp16": q, k, v, dout point at IEEE-half data, P and dS are rounded to half, the
 // five products are v_mfma_f32_16x16x32_f16; dq, dk, dv are written as bf16 either way — they are rounded accumulators).  In the half form dout
-// is the copy fb_prep_kernel staged, multiplied by the power of two `dscale` that brings the tensor's largest magnitude into (32, 64] —
+// is the copy fb_prep_kernel staged, multiplied by the power of two `dscale` that brings the tensor's largest magnitude into (2, 4] —
 // gradients of a mean-reduced loss are ~1e-6 and would vanish in half; the outputs are divided by it again.
 template <bool PRE, class TA>
 __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             float* const run_st = run + rbh * nqt * tile_f + (size_t)hh * 1024 + (size_t)lane * 4;
             auto chain_load = [&](int tau, f32x4 (&r4)[4]) FB_INLINE {
 #pragma unroll
-                for (int G = 0; G < 4; G++) r4[G] = fb_ld_l2(run_rs, run_vo + G * 1024, (unsigned)tau * (unsigned)(FB_RUN_TILE * 4));
+                for (int G = 0; G < 4; G++) r4[G] = fb_ld_l2(run_rs, run_vo + G * 1024, (unsigned)((FB_X & 8) ? 0 : tau) * (unsigned)(FB_RUN_TILE * 4));
             };
             auto tags_good = [&](f32x4 (&r4)[4]) FB_INLINE -> bool {       // every piece of the wave's slice carries the predecessor's number
                 unsigned bad = 0;
@@ -594,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                 for (int G = 0; G < 4; G++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) bad |= fb_f2u(r4[G][r]) ^ tag_of(id_pred, r);
+                if (FB_X & 32) return true;
                 return !__any((bad & 7u) != 0);
             };
             auto chain_commit = [&](int tau, f32x4 (&a)[4]) FB_INLINE {            // running sum (rb, tags verified) + this block's share -> next block, or the finished dQ
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                         f32x4 t;
 #pragma unroll
                         for (int r = 0; r < 4; r++) t[r] = fb_u2f((fb_f2u(a[G][r]) & ~7u) | tag_of(id_mine, r));
-                        fb_st_run(run_st + (size_t)tau * tile_f + G * 256, t);
+                        fb_st_run(run_st + (size_t)((FB_X & 8) ? 0 : tau) * tile_f + G * 256, t);
                     }
                 } else {
 #pragma unroll
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
 #pragma unroll
                     for (int r = 0; r < 4; r++) t[r] = fb_u2f(tag_of(id_mine, r));
 #pragma unroll
-                    for (int G = 0; G < 4; G++) fb_st_run(run_st + (size_t)tau * tile_f + G * 256, t);
+                    for (int G = 0; G < 4; G++) fb_st_run(run_st + (size_t)((FB_X & 8) ? 0 : tau) * tile_f + G * 256, t);
                 }
             };
             auto commit_dyn = [&](int tau) FB_INLINE {                             // the share of tile tau sits in ring slot tau & 3 (a wave-uniform switch)
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             bool inflight = false, aborted = false;
             auto chain_request = [&](int produced) FB_INLINE {                     // top of an iteration: tiles < produced have their share in the ring
                 if ((FB_X & 1) || inflight || done >= produced) return;
-                chain_load(done, rb);
+                if (!(FB_X & 64)) chain_load(done, rb);
                 inflight = true;
             };
             // returns true when the vector-memory operations it issued are exactly one tile's four running-tile stores

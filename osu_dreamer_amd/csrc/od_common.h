@@ -535,8 +535,8 @@ __device__ __forceinline__ void od_barrier_raw() { asm volatile("s_barrier" ::: 
 // od_det_flush folds the shadow into the fp32 destination before its first reader.  Values the shadow cannot hold (NaN, Inf, |v| >= 2^23)
 // take the float atomic, so a non-finite gradient stays visible.  det == NULL: the plain float atomic.
 struct OdDetRange { const float* base; long long count; long long* shadow; };
-struct OdDetTable { int n; int pad; OdDetRange r[14]; };
-__device__ __forceinline__ long long od_fix(float v) { return (long long)((double)v * 1099511627776.0); }       // 2^40; exact product, truncated
+struct OdDetTable { int n; int pad; OdDetRange r[20]; };      // 488 bytes: arena + two live plans' six buffers each + spare
+__device__ __forceinline__ long long od_fix(float v) { return llrint((double)v * 1099511627776.0); }       // 2^40; exact product, rounded to nearest (truncation biased every sum towards zero)
 __device__ __forceinline__ float od_unfix(long long s) { return (float)((double)s * (1.0 / 1099511627776.0)); }
 __device__ __forceinline__ void od_red_add(const OdDetTable* det, float* p, float v) {
     if (det && fabsf(v) < 8388608.f) {

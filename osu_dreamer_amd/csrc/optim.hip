@@ -104,6 +104,13 @@ extern "C" int od_ema_update(float* ema, const float* p, long n, float ema_decay
 
 extern "C" int od_sqnorm(const float* g, long n, float* out, const int* status, void* stream) {
     int blocks = (int)((n / 4 + 255) / 256); if (blocks > SQ_MAX_BLOCKS) blocks = SQ_MAX_BLOCKS; if (blocks < 1) blocks = 1;
+#if !defined(OD_EMU)
+    // the arrival counter is re-armed ON THE LAUNCH STREAM in front of every launch: a launch that was aborted (or killed by a fault) cannot
+    // leave it non-zero for the next one, which would then never see a last block and leave the norm at 0 — clip off, status lost.
+    // The scratch is process-global: launches on DIFFERENT streams at the same time are not supported (one optimizer norm at a time).
+    static unsigned* done_addr = [] { void* p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_sq_done)) == hipSuccess ? (unsigned*)p : (unsigned*)nullptr; }();
+    if (!done_addr || hipMemsetAsync(done_addr, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return OD_ERR_ARG;
+#endif
     OD_LAUNCH(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out, status);
     OD_CHECK_LAUNCH();
     return 0;

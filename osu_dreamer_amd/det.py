@@ -12,6 +12,7 @@ per arena segment.
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -53,34 +54,49 @@ def context(device: torch.device) -> Optional["DetContext"]:
 
 
 class DetContext:
+    """The registered ranges follow the LIFETIME of their buffers: a range is held through a weak reference to its tensor, and ranges
+    whose tensor has been freed (a Workspace the engine replaced on a new plan: the validation loader re-plans per map length) are dropped
+    — with their int64 shadows — at the next registration, so the C side's fixed table (od_common.h OdDetTable) only ever holds the live
+    plans' buffers.  A registration that does not fit leaves the previous table active and raises."""
+
     def __init__(self, device: torch.device):
         L = _lib.lib()
         self.device = device
         self.table = torch.zeros(int(L.cdll.od_det_table_bytes()), dtype=torch.uint8, device=device)
-        self.ranges: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.ranges: Dict[Tuple[int, int], Tuple["weakref.ref[torch.Tensor]", torch.Tensor]] = {}
         L.od_det_clear()
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
 
-    def _upload(self):
+    def _upload(self, ranges):
+        """Rebuild the C table from `ranges`; raises (HipKernelError) when they do not fit."""
         L = _lib.lib()
         L.od_det_clear()
-        for t, sh in self.ranges.values():
-            L.od_det_register(t.data_ptr(), t.numel(), sh.data_ptr())
+        for (ptr, n), (_, sh) in ranges.items():
+            L.od_det_register(ptr, n, sh.data_ptr())
         L.od_det_enable(self.table.data_ptr(), self._stream())
+
+    def live_ranges(self):
+        return {k: v for k, v in self.ranges.items() if v[0]() is not None}
 
     def register(self, t: torch.Tensor):
         """`t`: a contiguous fp32 buffer kernels accumulate into.  Idempotent; a buffer that was re-allocated replaces its old entry."""
         assert t.dtype == torch.float32 and t.is_contiguous()
         key = (t.data_ptr(), t.numel())
-        if key in self.ranges:
+        cur = self.ranges.get(key)
+        if cur is not None and cur[0]() is t:
             return
-        # drop entries whose tensor is gone or overlaps the new one (a re-allocated arena)
+        # drop entries whose tensor is gone (freed workspaces) or overlaps the new one (a re-allocated arena, a recycled address)
         lo, hi = t.data_ptr(), t.data_ptr() + t.numel() * 4
-        self.ranges = {k: v for k, v in self.ranges.items() if not (k[0] < hi and lo < k[0] + k[1] * 4)}
-        self.ranges[key] = (t, torch.zeros(t.numel(), dtype=torch.int64, device=t.device))
-        self._upload()
+        new = {k: v for k, v in self.live_ranges().items() if not (k[0] < hi and lo < k[0] + k[1] * 4)}
+        new[key] = (weakref.ref(t), torch.zeros(t.numel(), dtype=torch.int64, device=t.device))
+        try:
+            self._upload(new)
+        except Exception:
+            self._upload(self.live_ranges())      # the previous table stays active
+            raise
+        self.ranges = new
 
     def flush(self, t: torch.Tensor):
         """Fold the shadow of `t` (a registered buffer or a contiguous slice of one) into it: call before its first reader."""

@@ -185,7 +185,14 @@ class DenoiserEngine:
         self.M, self.Ma = B * L, Ba * L
         self.attn_f16 = getattr(self.model, "attn_dtype", None) == torch.float16
         if self.attn_f16 and (dtype != torch.bfloat16 or self.hd != 64):
-            raise NotImplementedError("attn_dtype = float16 needs compute_dtype = bfloat16 and head_dim 64")
+            # the half-operand core exists for bf16 compute and head_dim 64 only; anything else — an fp32 no-grad forward or sample() after a
+            # `precision: 16-mixed` fit, a model with another head_dim — runs the attention of the compute dtype, said once
+            if not getattr(self, "_warned_f16_fallback", False):
+                import warnings
+                warnings.warn(f"attn_dtype = float16 applies to compute_dtype bfloat16 with head_dim 64; this plan (dtype {dtype}, head_dim "
+                              f"{self.hd}) runs its attention in {dtype}")
+                self._warned_f16_fallback = True
+            self.attn_f16 = False
         return self.ws
 
     def buf(self, name, shape, dtype=None):
@@ -501,7 +508,10 @@ class DenoiserEngine:
         launch were skipped on the device."""
         if self._attn_ws is None:
             return
-        code = self._attn_ws.status()
+        # every cached shape's workspace (a sticky error on the shape a ragged last batch uses must not wait for that shape's turn: ADVICE r5)
+        code = 0
+        for ws in {id(w): w for w in [self._attn_ws, *self._attn_ws_cache.values()]}.values():
+            code = code or ws.status()
         if code != 0:
             raise RuntimeError(f"od_flash_attn_bwd_fused status {code}: {self.ATTN_STATUS.get(code, '?')}; the optimizer steps since then "
                                "were skipped.  OD_ATTN_BWD_FUSED=0 selects the two-kernel backward.")

@@ -900,7 +900,7 @@ def test_gemm_tn_blocks_drops_the_padding(dev, M, blk, valid, K):
 
 
 def test_det_api_refuses_what_it_cannot_do(dev):
-    """od_det_*: a flush outside every registered range is an error (not a silent no-op), the table holds at most 14 ranges, and clearing it
+    """od_det_*: a flush outside every registered range is an error (not a silent no-op), the table holds a fixed number of ranges (20), and clearing it
     switches the mode off (a later kernel uses the plain float atomic again)."""
     from osu_dreamer_amd import _lib, det
     L = _lib.lib()
@@ -913,11 +913,13 @@ def test_det_api_refuses_what_it_cannot_do(dev):
             L.od_det_flush(b.data_ptr(), b.numel(), ops._stream(b))
         with pytest.raises(_lib.HipKernelError):
             L.od_det_flush(a.data_ptr() + 4 * 32, 64, ops._stream(a))          # runs past the end of the range
-        keep = [torch.zeros(8, device=dev) for _ in range(13)]
+        cap = (L.cdll.od_det_table_bytes() - 8) // 24
+        keep = [torch.zeros(8, device=dev) for _ in range(cap - 1)]
         for t in keep:
             ctx.register(t)
         with pytest.raises(_lib.HipKernelError):
-            ctx.register(torch.zeros(8, device=dev))                           # the 15th range
+            ctx.register(torch.zeros(8, device=dev))                           # one more than the table holds
+        assert len(ctx.live_ranges()) == cap                                   # ... and the previous table is still the active one
     finally:
         det.force(None)
     G, A = torch.randn(70, 16).to(dev), torch.randn(70, 8).to(dev)

@@ -387,8 +387,8 @@ def test_deterministic_mode_matches_the_plain_step(dev):
             out[mode] = (losses, g1, model.arena.data.detach().cpu().clone())
             if mode != "plain":
                 ctx = det.context(dev)
-                assert len(ctx.ranges) >= 6
-                for t, sh in ctx.ranges.values():
+                assert len(ctx.live_ranges()) >= 6
+                for t, sh in ctx.live_ranges().values():
                     assert int(sh.abs().max()) == 0                   # every shadow was folded in
     finally:
         det.force(None)
@@ -396,6 +396,53 @@ def test_deterministic_mode_matches_the_plain_step(dev):
     assert out["det"][0] == pytest.approx(out["plain"][0], rel=1e-6)
     assert rel_l2(out["det"][1], out["plain"][1]) < 2e-6
     assert rel_l2(out["det"][2], out["plain"][2]) < 1e-6
+
+
+def test_deterministic_mode_survives_replanning(dev):
+    """under OD_DETERMINISTIC the validation loader (batch 1, whole maps of varying length) makes the engine re-plan per batch,
+    and every plan registers the workspace buffers its kernels accumulate into.  The registrations follow the buffers' lifetime (det.py:
+    weak references, dead plans pruned), so many plan changes neither exhaust the C side's fixed table nor leak shadows — and a training step
+    after them is still bit-identical to the same step before them."""
+    from osu_dreamer_amd import det
+    d = O.TINY
+    P = O.init_params(d, seed=31)
+    try:
+        det.force(True)
+        tr = make_trainer(d, P, dev)
+        model = tr.diffusion
+        opt = tr.configure_optimizers()["optimizer"]
+        opt.max_grad_norm = 1.0
+
+        def step_grad(L):
+            data = {k: v.to(dev) for k, v in O.synthetic_batch(d, 2, L, seed=32 + L).items()}
+            opt.zero_grad()
+            loss, _ = tr(model, data["h"], data["z"], data["s"], None, t=data["t"], x0=data["x0"])
+            loss.backward()
+            return float(loss.detach()), model.arena.grad.detach().cpu().clone()
+
+        first = step_grad(24)
+        ctx = det.context(dev)
+        for L in (17, 40, 33, 56, 24, 29, 48, 21, 64, 37):          # ten more plans: 3-6 registrations each
+            step_grad(L)
+            assert len(ctx.live_ranges()) <= 14, len(ctx.live_ranges())
+        again = step_grad(24)
+        assert again[0] == first[0] and torch.equal(again[1], first[1])
+        n_cap = int(_table_capacity())
+        # a registration that does not fit raises AND leaves the previous table active (the mode keeps working)
+        keep = [torch.zeros(8, device=dev) for _ in range(n_cap + 2)]
+        with pytest.raises(Exception):
+            for t in keep:
+                ctx.register(t)
+        del keep
+        after = step_grad(24)
+        assert after[0] == first[0] and torch.equal(after[1], first[1])
+    finally:
+        det.force(None)
+
+
+def _table_capacity():
+    from osu_dreamer_amd import _lib
+    return (_lib.lib().cdll.od_det_table_bytes() - 8) // 24
 
 
 def test_failed_attention_backward_is_caught_in_every_step(dev, monkeypatch):

@@ -6,8 +6,8 @@ under bf16 autocast.  Held to it:
   * the oracle (CPU restatement; `-m "not gpu"`): every step's loss, clip norm and learning rate, the final weights and EMA weights;
   * the HIP path (DiffusionTrainer + FusedAdamWEMA through the C ABI): a 10-step prefix on the emulator build, all 40 steps on the GPU —
       fp32:  loss within 1e-4 (relative) at EVERY step, learning rate exactly, final weights / EMA: per tensor the RMS distance to the
-             reference's tensor <= 2e-5 of the tensor's RMS + 0.5 % of how far 40 steps of training moved it (an element whose gradient is
-             ~0 takes AdamW's sign-like first steps, +-lr whatever the magnitude, so the bound scales with the move, not with the weight);
+             reference's tensor <= 1e-5 of the tensor's RMS + 0.1 % of how far 40 steps of training moved it (an element whose gradient is
+             ~0 takes AdamW's sign-like first steps, +-lr whatever the magnitude, so the bound scales with the move, not with the weight; measured on the MI355X: 7-9 % of it);
       bf16:  per step |loss - ref_bf16| <= 3 x |ref_bf16 - ref_f32| + 2e-3 |ref_f32| (the reference's own bf16-vs-fp32 drift is the
              yardstick, as in test_model_parity), final weights within 3 x the reference's own bf16-vs-fp32 weight distance (+ 1e-4 norm).
 """
@@ -47,7 +47,7 @@ def sub(w):
 
 
 def check_weights(fx, tag, P0, weights, ema, k_drift=0.0, label=""):
-    """per tensor: |sub-sample - reference's| <= 2e-5 |w| + 0.5 % |w_final - w_0| (+ k_drift x the reference's own bf16-vs-fp32 distance), as RMS over
+    """per tensor: |sub-sample - reference's| <= 1e-5 |w| + 0.1 % |w_final - w_0| (+ k_drift x the reference's own bf16-vs-fp32 distance), as RMS over
     the sub-sample"""
     worst = 0.0
     for k in weights:
@@ -56,7 +56,7 @@ def check_weights(fx, tag, P0, weights, ema, k_drift=0.0, label=""):
         for pre, w in (("p", weights[k]), ("ema", ema[k])):
             ref = fx[f"{tag}.{pre}sub." + k]
             rms_w = float(fx[f"{tag}.{pre}norm." + k]) / max(1.0, float(P0[k].numel())) ** 0.5
-            tol = 2e-5 * rms_w + 5e-3 * moved + 1e-7
+            tol = 1e-5 * rms_w + 1e-3 * moved + 1e-7
             if k_drift:
                 drift = float((fx[f"bf16.{pre}sub." + k] - fx[f"f32.{pre}sub." + k]).norm()) / n_el ** 0.5
                 tol += k_drift * drift
