@@ -878,6 +878,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(const bf16_t* __rest
                 const int gm_lo = m0 + wm * 128 + j * 16 + xr, gm_hi = gm_lo + 8;
                 // rows 8..15: lanes x >= 8 write their OWN p = 2 pp piece at the line's first half, lanes x < 8 the partner's p = 2 pp + 1 piece
                 const int gn_hi = n0 + wn * 128 + 64 * pp + 32 * (1 - xh) + 8 * g;
+                // (OD_W4_X & 32, timing only: every second workgroup of an XCD keeps its results in registers — does a CU's store phase get
+                // shorter when half the chip is silent?  profiles/r06d_nt_store_contention.txt)
+                const bool silent = (OD_W4_X & 32) && ((blockIdx.x >> 3) & 1);
+                if (silent) { asm volatile("" :: "v"(lo), "v"(hi)); continue; }
                 if (gn < N && gm_lo < M) {
                     T* dst = C + (size_t)gm_lo * ldc + gn;
                     if (nt_store) od_st16_nt(dst, lo); else *(u32x4*)dst = lo;

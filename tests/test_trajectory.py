@@ -9,7 +9,7 @@ under bf16 autocast.  Held to it:
              reference's tensor <= 1e-5 of the tensor's RMS + 0.1 % of how far 40 steps of training moved it (an element whose gradient is
              ~0 takes AdamW's sign-like first steps, +-lr whatever the magnitude, so the bound scales with the move, not with the weight; measured on the MI355X: 7-9 % of it);
       bf16:  per step |loss - ref_bf16| <= 3 x |ref_bf16 - ref_f32| + 2e-3 |ref_f32| (the reference's own bf16-vs-fp32 drift is the
-             yardstick, as in test_model_parity), final weights within 3 x the reference's own bf16-vs-fp32 weight distance (+ 1e-4 norm).
+             yardstick, as in test_model_parity), final weights within 3 x the reference's own bf16-vs-fp32 weight distance per tensor (+ 2 % of the tensor's move).
 """
 import os
 
@@ -57,9 +57,9 @@ def check_weights(fx, tag, P0, weights, ema, k_drift=0.0, label=""):
             ref = fx[f"{tag}.{pre}sub." + k]
             rms_w = float(fx[f"{tag}.{pre}norm." + k]) / max(1.0, float(P0[k].numel())) ** 0.5
             tol = 1e-5 * rms_w + 1e-3 * moved + 1e-7
-            if k_drift:
+            if k_drift:                          # bf16: the reference's own bf16-vs-fp32 distance on this tensor is the yardstick, 2 % of the move the floor
                 drift = float((fx[f"bf16.{pre}sub." + k] - fx[f"f32.{pre}sub." + k]).norm()) / n_el ** 0.5
-                tol += k_drift * drift
+                tol += k_drift * drift + 0.02 * moved
             err = float((sub(w) - ref).norm()) / n_el ** 0.5
             assert err <= tol, (label, tag, pre, k, err, tol)
             worst = max(worst, err / tol)
