@@ -40,7 +40,13 @@ constexpr int FB_DS = FB_KB * 128;                // dS of one tile: [192 keys][
 #define FB_NSLOTS 4
 #endif
 constexpr int FB_SLOTS = FB_NSLOTS;                          // (batch, head)s per XCD whose running tiles exist at a time (two are in flight; the buffer is reused)
-constexpr int FB_RUN_TILE = 4 * 4 * 64 * 4;          // floats of one (batch-head, query tile) of the running buffer: 4 waves x 4 pieces x 64 lanes x 4
+#ifndef FB_PACK
+#define FB_PACK 1      // 1: the running tile travels as 22-bit values (sign, exponent, 13 mantissa bits), 16 of them + the write number in THREE 16-byte
+                       // pieces per lane instead of four: 0.75 x the chain's bytes and vector-memory instructions (round 6, see fb_pack): 21.01 -> 20.69 ms
+                       // per call, 320.4 -> 317.9 ms per step on one box (profiles/r06e_chain_pack.txt); 0 = four fp32 pieces with 3 tag bits per dword
+#endif
+constexpr int FB_NP = FB_PACK ? 3 : 4;               // 16-byte pieces per lane and tile
+constexpr int FB_RUN_TILE = 4 * FB_NP * 64 * 4;      // floats of one (batch-head, query tile) of the running buffer: 4 waves x FB_NP pieces x 64 lanes x 4
 constexpr int FB_KST = 2 * FB_STAGE + 2 * FB_DS;     // the key block's K rows, staged once per job for the query waves (same image as a dS tile)
 constexpr int FB_SMEM = FB_KST + FB_DS + 16;
 
@@ -534,7 +540,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             //   it = tau + 2: (top) load the running tile; (end) tags good -> running + share -> tagged stores (last key block: the bf16 dQ)
             // A key block therefore trails its predecessor by ~1.5 iterations; consecutive key blocks of a (batch, head) START nqt / (CUs per XCD)
             // iterations apart (they are consecutive jobs of one queue), which has to stay above that: the host routes short sequences elsewhere.
-            f32x4 acc[4][4], rb[4];
+            f32x4 acc[4][4], rb[FB_NP];
+            bool poisoned = false;                                        // the tile in rb could not be had (chain_try): its values are NaN
             unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};       // FB_PROF cycle counters
             const size_t tile_f = FB_RUN_TILE;                           // floats of one (bh, tile): [hh][G][lane][4]
             const bool last = kblk == nkb - 1;
@@ -589,22 +596,89 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
             };
             const size_t rbh = (size_t)od_uniform(xcc * FB_SLOTS + slot);
             const fb_rsrc_t run_rs = fb_make_rsrc(run + rbh * nqt * tile_f, (unsigned)((size_t)nqt * tile_f * 4));
-            const unsigned run_vo = (unsigned)((hh * 1024 + lane * 4) * 4);
-            float* const run_st = run + rbh * nqt * tile_f + (size_t)hh * 1024 + (size_t)lane * 4;
-            auto chain_load = [&](int tau, f32x4 (&r4)[4]) FB_INLINE {
+            const unsigned run_vo = (unsigned)((hh * (FB_NP * 256) + lane * 4) * 4);
+            float* const run_st = run + rbh * nqt * tile_f + (size_t)hh * (FB_NP * 256) + (size_t)lane * 4;
+            auto chain_load = [&](int tau, f32x4 (&r4)[FB_NP]) FB_INLINE {
 #pragma unroll
-                for (int G = 0; G < 4; G++) r4[G] = fb_ld_l2(run_rs, run_vo + G * 1024, (unsigned)((FB_X & 8) ? 0 : tau) * (unsigned)(FB_RUN_TILE * 4));
+                for (int G = 0; G < FB_NP; G++) r4[G] = fb_ld_l2(run_rs, run_vo + G * 1024, (unsigned)((FB_X & 8) ? 0 : tau) * (unsigned)(FB_RUN_TILE * 4));
             };
-            auto tags_good = [&](f32x4 (&r4)[4]) FB_INLINE -> bool {       // every piece of the wave's slice carries the predecessor's number
+            auto tags_good = [&](f32x4 (&r4)[FB_NP]) FB_INLINE -> bool {   // every piece of the wave's slice carries the predecessor's number
                 unsigned bad = 0;
+#if FB_PACK
+#pragma unroll
+                for (int P = 0; P < FB_NP; P++) bad |= ((fb_f2u(r4[P][3]) >> 14) ^ id_pred) & 0x3ffu;      // ten bits of the number in every piece
+                if (FB_X & 32) return true;
+                return !__any(bad != 0);
+#else
 #pragma unroll
                 for (int G = 0; G < 4; G++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) bad |= fb_f2u(r4[G][r]) ^ tag_of(id_pred, r);
                 if (FB_X & 32) return true;
                 return !__any((bad & 7u) != 0);
+#endif
             };
+#if FB_PACK
+            // The packed tile.  A lane's 16 values (feature tile G = i / 4, row r = i % 4) travel as 22-bit floats u = (bits + 0x200) >> 10 —
+            // sign, exponent, 13 mantissa bits, rounded to nearest: 2^-14 relative per hop, ~2^-12 over the 43 hops of a chain, against the
+            // 2^-9 of the bf16 the sum is rounded to at the end.  Piece P (16 bytes, the unit the memory system moves) holds values 5 P .. 5 P + 4
+            // in bits [0, 110), ten bits of the write number in [110, 120) and 8 / 7 / 7 bits of value 15 in [120, 128): every piece still proves
+            // which write it belongs to, and a tile is three vector-memory instructions per wave and direction instead of four.
+            auto fb_unpack = [&](const f32x4 (&r4)[FB_NP], float (&v)[16]) FB_INLINE {
+                unsigned last = 0;
+#pragma unroll
+                for (int P = 0; P < 3; P++) {
+                    const unsigned d0 = fb_f2u(r4[P][0]), d1 = fb_f2u(r4[P][1]), d2 = fb_f2u(r4[P][2]), d3 = fb_f2u(r4[P][3]);
+                    v[5 * P + 0] = fb_u2f(d0 << 10);
+                    v[5 * P + 1] = fb_u2f(((d0 >> 22) | (d1 << 10)) << 10);
+                    v[5 * P + 2] = fb_u2f(((d1 >> 12) | (d2 << 20)) << 10);
+                    v[5 * P + 3] = fb_u2f((d2 << 8) & 0xfffffc00u);
+                    v[5 * P + 4] = fb_u2f(((d2 >> 24) | (d3 << 8)) << 10);
+                    last |= (d3 >> 24) << (P == 0 ? 0 : P == 1 ? 8 : 15);
+                }
+                v[15] = fb_u2f(last << 10);
+            };
+            auto fb_pack = [&](const float (&v)[16], unsigned id, f32x4 (&out)[FB_NP]) FB_INLINE {
+                unsigned u[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) u[i] = (fb_f2u(v[i]) + 0x200u) >> 10;
+#pragma unroll
+                for (int P = 0; P < 3; P++) {
+                    const unsigned a0 = u[5 * P], a1 = u[5 * P + 1], a2 = u[5 * P + 2], a3 = u[5 * P + 3], a4 = u[5 * P + 4];
+                    const unsigned ex = P == 0 ? (u[15] & 0xffu) : P == 1 ? ((u[15] >> 8) & 0x7fu) : (u[15] >> 15);
+                    out[P][0] = fb_u2f(a0 | (a1 << 22));
+                    out[P][1] = fb_u2f((a1 >> 10) | (a2 << 12));
+                    out[P][2] = fb_u2f((a2 >> 20) | (a3 << 2) | (a4 << 24));
+                    out[P][3] = fb_u2f((a4 >> 8) | ((id & 0x3ffu) << 14) | (ex << 24));
+                }
+            };
+#endif
             auto chain_commit = [&](int tau, f32x4 (&a)[4]) FB_INLINE {            // running sum (rb, tags verified) + this block's share -> next block, or the finished dQ
+#if FB_PACK
+                {
+                    float rv[16];
+                    fb_unpack(rb, rv);
+                    if (poisoned) {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) rv[i] = fb_poison();
+                    }
+#pragma unroll
+                    for (int G = 0; G < 4; G++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) a[G][r] += rv[4 * G + r];                       // (the first key block adds the marker tile's zeros)
+                }
+                if (!last) {
+                    float sv[16];
+#pragma unroll
+                    for (int G = 0; G < 4; G++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) sv[4 * G + r] = a[G][r];
+                    f32x4 t3[FB_NP];
+                    fb_pack(sv, id_mine, t3);
+#pragma unroll
+                    for (int P = 0; P < FB_NP; P++) fb_st_run(run_st + (size_t)((FB_X & 8) ? 0 : tau) * tile_f + P * 256, t3[P]);
+                } else {
+#else
 #pragma unroll
                 for (int G = 0; G < 4; G++)
 #pragma unroll
@@ -618,6 +692,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                         fb_st_run(run_st + (size_t)((FB_X & 8) ? 0 : tau) * tile_f + G * 256, t);
                     }
                 } else {
+#endif
 #pragma unroll
                     for (int G = 0; G < 4; G++) {
                         const int qrow = tau * 64 + qcol[gi_of(G)];
@@ -629,10 +704,14 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                         }
                     }
                     f32x4 t;                                             // the marker "this tile has been read" (tags on zeros): the slot's next user waits for it
+#if FB_PACK
+                    t[0] = t[1] = t[2] = 0.f; t[3] = fb_u2f((id_mine & 0x3ffu) << 14);
+#else
 #pragma unroll
                     for (int r = 0; r < 4; r++) t[r] = fb_u2f(tag_of(id_mine, r));
+#endif
 #pragma unroll
-                    for (int G = 0; G < 4; G++) fb_st_run(run_st + (size_t)((FB_X & 8) ? 0 : tau) * tile_f + G * 256, t);
+                    for (int G = 0; G < FB_NP; G++) fb_st_run(run_st + (size_t)((FB_X & 8) ? 0 : tau) * tile_f + G * 256, t);
                 }
             };
             auto commit_dyn = [&](int tau) FB_INLINE {                             // the share of tile tau sits in ring slot tau & 3 (a wave-uniform switch)
@@ -692,9 +771,11 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_fused_kernel(const bf16_t* _
                     if (aborted) {
                         if (lane == 0) fb_flag_store(&sync->err, 3);
 #pragma unroll
-                        for (int G = 0; G < 4; G++) rb[G] = (f32x4)(fb_poison());
+                        for (int G = 0; G < FB_NP; G++) rb[G] = (f32x4)(fb_poison());
+                        poisoned = true;
                     }
                     commit_dyn(done);
+                    poisoned = false;
                     done++;
                 }
                 return four;
