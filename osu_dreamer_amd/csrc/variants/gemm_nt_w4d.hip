@@ -7,8 +7,14 @@
 //     bound by the chip's write rate for this pattern, not by an exposed epilogue: there is nothing to hide it behind.
 //   * this build also computes WRONG results on the GPU (NaNs; right on the emulator): a hazard around the asm MFMAs / accumulator
 //     re-initialisation that was not chased once the timing had answered the question.
-// To build it again: paste the kernel in front of tn_off() in gemm.hip, restore the dispatch (launch_nt: OD_NT_W4D_MAX_K, grid
-// ((M+255)/256 rounded to 8) x ceil(N/128), 98304 bytes of LDS) — git show of the commit that added this file has both.
+// To build it again: paste the kernel in front of tn_off() in gemm.hip and put this dispatch in launch_nt, in front of the gemm_nt_w4_kernel launches:
+//     static const int w4d_max_k = od_env_int("OD_NT_W4D_MAX_K", 0);
+//     if (epi == OD_EPI_NONE && K >= 512 && K <= w4d_max_k && !rp.f16) {
+//         const int grid3 = ((tm2 + 7) / 8) * 8 * ((N + 127) / 128);
+//         OD_LAUNCH_DYN((gemm_nt_w4d_kernel<0>), dim3(grid3 < pgrid ? grid3 : pgrid), dim3(256), 98304, st, A, lda, W, ldw, bias, C, ldc, M, N, K, nt_store);
+//         OD_CHECK_LAUNCH();
+//         return 0;
+//     }
 #if 0
 // ---------------------------------------------------------------------------------------------------------------------------------
 // gemm_nt_w4d_kernel: the 4-wave persistent organisation with TWO accumulator sets (round 6).
