@@ -309,8 +309,9 @@ def roofline_of_dominant_kernel(tr, B, L):
         "achieved": round(ach_bwd, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach_bwd / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "traffic_note": ("fabric-side bytes of the call (L2 misses + write-through stores).  The operands are ~4.3 GB (q, k, v, o, dO read once; dq, dk, dv written once); "
-                         "the rest is the dQ chain: a running fp32 tile of 16 KB per query tile handed key block -> key block, "
-                         f"2 x 16 KB x {B * H * ((L + 63) // 64) * (((L + 191) // 192) - 1) / 1e6:.2f} M hand-offs through an L2 that writes every store through (DESIGN.md section 3, round 4)"
+                         "the rest is the dQ chain: a running tile of 12 KB per query tile (16 x 22-bit values + the write number in three 16-byte pieces per lane; "
+                         "round 6: 16 KB of fp32 before) handed key block -> key block through the XCD's L2 with non-temporal loads, "
+                         f"2 x 12 KB x {B * H * ((L + 63) // 64) * (((L + 191) // 192) - 1) / 1e6:.2f} M hand-offs, most of which stay in the L2 (DESIGN.md sections 3 and 9)"
                          if fused else None),
         "ms_per_launch": round(t_bwd * 1e3, 3),
         "flops_counted": f"algorithmic: {BWD_PASSES_ALGORITHMIC} passes x 2*B*H*L^2*hd",

@@ -691,6 +691,177 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
     }
 }
 
+#ifndef OD_FWD16X
+#define OD_FWD16X 0       // 1 (A/B build, round 6): bf16 / hd 64 / pre-multiplied q runs flash_fwd16x_kernel — flash_fwd32_kernel's structure on 16x16x32 tiles
+#endif
+#if OD_FWD16X
+// flash_fwd32_kernel's STRUCTURE — buffer-addressed asm LDS-DMA (rows past L read as zero), compile-time stage addresses (loop unrolled by two),
+// the lazy log2-domain reference with the running row SUM as the overflow guard (no per-tile row maximum), scalar row sums — on
+// v_mfma_f32_16x16x32_bf16 tiles in flash_fwd_kernel's formulation (S^T = K Q^T: a softmax row is an accumulator column; P^T feeds O^T += V^T P^T
+// through a k-permutation the V transpose reads reproduce).  Per wave and 64-key tile: 32 MFMAs of 16 cycles where the 32x32x16 form issues
+// 16 of 32, the same 8 + 16 LDS fragment reads, the same exponentials.  VERDICT r5 item 4: "build the thing, or retire the question with a
+// measurement" — profiles/r06g_ab_fwd16x.txt.  bf16, head_dim 64, q pre-multiplied by scale * log2(e).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void flash_fwd16x_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                                  const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
+                                                                  float* __restrict__ lse, int B, int H, int L) {
+    using T = bf16_t;
+    using St = Stage<bf16_t, 64>;
+    constexpr int HD = 64, NQT = 2, QB = NW * 32, STAGE = 2 * St::BYTES;
+    static_assert(NW == 4, "the K / V tiles are streamed as 2 + 2 one-KiB pieces per wave");
+    OD_DYN_SMEM(smem);
+    const int nqt = (L + QB - 1) / QB;
+    int qt, bh;
+    if (!attn_block_coords(nqt, B * H, qt, bh)) return;
+    const int b = bh / H, h = bh % H;
+    const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), x = lane & 15, g = lane >> 4;
+    const bf16_t* qb = q + (size_t)b * L * ldq + h * HD;
+    const int q0 = qt * QB + wave * 32;
+    const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
+    const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
+    // piece = 8 rows x 128 B, tile_off<128>'s swizzle (slot ^ (row & 7), row & 7 = lane >> 3) applied on the SOURCE column; a wave moves pieces w, w + 4
+    const int prow = lane >> 3, pslot = (lane & 7) ^ prow;
+    const unsigned vk = (unsigned)((wave * 8 + prow) * ldk * 2 + pslot * 16), vv = (unsigned)((wave * 8 + prow) * ldv * 2 + pslot * 16);
+    auto dma = [&](int kt, unsigned char* st) {
+        const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u, sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
+        od_buffer_lds16(rk, vk, sk, st + wave * 1024);
+        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
+        od_buffer_lds16(rv, vv, sv, st + St::BYTES + wave * 1024);
+        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + St::BYTES + (wave + 4) * 1024);
+    };
+    od_frag<T> fq[NQT][2];
+#pragma unroll
+    for (int qi = 0; qi < NQT; qi++) {
+        int row = q0 + qi * 16 + x; row = row < L ? row : L - 1;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) od_frag_load(fq[qi][s2], qb + (size_t)row * ldq + s2 * 32 + g * 8);
+    }
+    f32x4 oacc[NQT][4];
+    float mref[NQT], lrun[NQT];                     // mref in log2 units (q is pre-multiplied)
+#pragma unroll
+    for (int qi = 0; qi < NQT; qi++) {
+        mref[qi] = 0.f; lrun[qi] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) oacc[qi][dt] = (f32x4)(0.f);
+    }
+    const int nkt = (L + 63) / 64;
+    OD_DRAIN_VMEM();                                // the Q fragments: a wait hipcc sees (see flash_fwd32_kernel)
+    dma(0, smem);
+    OD_WAIT_VMCNT(0);
+    __syncthreads();
+    auto tile = [&](int kt, const unsigned char* st, unsigned char* st_next, auto masked_t, auto first_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
+        constexpr bool FIRST = decltype(first_t)::value;
+        if (kt + 1 < nkt) dma(kt + 1, st_next);
+        const unsigned char* tK = st;
+        const unsigned char* tV = st + St::BYTES;
+        // S^T tiles: rows = keys (4 tiles of 16), cols = queries; the accumulators start at -reference
+        f32x4 e[NQT][4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; t4++) {
+            od_frag<T> fk[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) frag_contig<128>(fk[s2], tK, t4 * 16 + x, s2 * 32 + g * 8);
+#pragma unroll
+            for (int qi = 0; qi < NQT; qi++) {
+                f32x4 a = (f32x4)(-mref[qi]);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) a = od_mma(fk[s2], fq[qi][s2], a);
+                e[qi][t4] = a;
+            }
+        }
+        if constexpr (MASKED) {    // ragged last tile only: keys >= L
+#pragma unroll
+            for (int qi = 0; qi < NQT; qi++)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (kt * 64 + t4 * 16 + 4 * g + r >= L) e[qi][t4][r] = NEG_BIG;
+        }
+        od_frag<T> fp[NQT][2];
+#pragma unroll
+        for (int qi = 0; qi < NQT; qi++) {
+            auto exact = [&]() {                    // move the reference to the row maximum (first tile; later only when the guard trips)
+                float m = NEG_BIG;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) m = fmaxf(m, e[qi][t4][r]);
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                const float d = FIRST ? m : fmaxf(m, 0.f);
+                if constexpr (!FIRST) {
+                    const float alpha = od_exp2(-d);
+                    lrun[qi] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 4; dt++) oacc[qi][dt] *= alpha;
+                }
+                mref[qi] += d;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++) e[qi][t4] -= d;
+            };
+            float ps;
+            auto probs = [&]() {
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                for (int t4 = 0; t4 < 4; t4++) {
+                    const float p0 = od_exp2(e[qi][t4][0]), p1 = od_exp2(e[qi][t4][1]), p2 = od_exp2(e[qi][t4][2]), p3 = od_exp2(e[qi][t4][3]);
+                    acc0 += p0; acc1 += p1; acc0 += p2; acc1 += p3;
+                    od_frag_set4(fp[qi][t4 >> 1], t4 & 1, p0, p1, p2, p3);
+                }
+                ps = acc0 + acc1;
+            };
+            if constexpr (FIRST) { exact(); probs(); }
+            else {
+                probs();
+                if (__any(!(ps < OD_FWD32_GUARD))) { exact(); probs(); }       // wave-uniform, rare
+            }
+            lrun[qi] += ps;
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                od_frag<T> fv;
+                frag_cols<128, 128>(fv, tV, tV, dt * 16, x, u, g);
+#pragma unroll
+                for (int qi = 0; qi < NQT; qi++) oacc[qi][dt] = od_mma(fv, fp[qi][u], oacc[qi][dt]);
+            }
+        OD_WAIT_VMCNT(0);
+        __syncthreads();
+    };
+    unsigned char* const s0 = smem;
+    unsigned char* const s1 = smem + STAGE;
+    const int nfull = L / 64;
+    if (nfull > 0) tile(0, s0, s1, std::false_type{}, std::true_type{});
+    else tile(0, s0, s1, std::true_type{}, std::true_type{});
+    int kt = 1;
+    for (; kt + 1 < nfull; kt += 2) {
+        tile(kt, s1, s0, std::false_type{}, std::false_type{});
+        tile(kt + 1, s0, s1, std::false_type{}, std::false_type{});
+    }
+    if (kt < nfull) { tile(kt, s1, s0, std::false_type{}, std::false_type{}); kt++; }
+    if (nfull > 0 && nfull < nkt) { if (kt & 1) tile(kt, s1, s0, std::true_type{}, std::false_type{}); else tile(kt, s0, s1, std::true_type{}, std::false_type{}); }
+#pragma unroll
+    for (int qi = 0; qi < NQT; qi++) {
+        float l = lrun[qi];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.f / l;
+        const int row = q0 + qi * 16 + x;
+        if (row < L) {
+            bf16_t* orow = o + ((size_t)b * L + row) * ldo + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+                st4(orow + dt * 16 + 4 * g, oacc[qi][dt][0] * inv, oacc[qi][dt][1] * inv, oacc[qi][dt][2] * inv, oacc[qi][dt][3] * inv);
+            if (g == 0) lse[((size_t)b * H + h) * L + row] = (mref[qi] + log2f(l)) * LN2;
+        }
+    }
+}
+#endif
+
 // (An 8-wave ping-pong arrangement of this kernel — two wave groups alternating MFMA and softmax phases behind bare barriers, K/V in a
 // 4-deep LDS ring — measured 8.36 ms against 7.9-8.1 and was removed: profiles/r02g_ab_pingpong.txt.)
 
@@ -1071,6 +1242,15 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     } else {
 #ifndef OD_FWD32_NW
 #define OD_FWD32_NW 4     // waves per workgroup of the bf16 / hd 64 forward (8: one workgroup per CU, the K / V tiles staged once for 256 queries; A/B)
+#endif
+#if OD_FWD16X
+    if constexpr (std::is_same<T, bf16_t>::value && HD == 64 && PRE) {
+        const int grid = attn_grid((L + 127) / 128, B * H);
+        OD_LAUNCH_DYN((flash_fwd16x_kernel<4>), dim3(grid), dim3(256), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq,
+                      (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L);
+        OD_CHECK_LAUNCH();
+        return 0;
+    }
 #endif
     if constexpr (OD_FWD32 && std::is_same<T, bf16_t>::value && HD == 64) {
         constexpr int NW = OD_FWD32_NW, NQB = OD_FWD32_NQB;

@@ -186,8 +186,23 @@ template <> __device__ __forceinline__ void od_st8_nt<bf16_t>(bf16_t* p, const f
 #if defined(OD_EMU)
 __device__ __forceinline__ void od_st16_nt(void* p, u32x4 r) { *(u32x4*)p = r; }
 #else
+// OD_ST16_POLICY (A/B, round 6: profiles/r06g_nt_store_policy.txt): cache policy of the GEMMs' streaming output stores — 0 = nt (the default), 1 = sc1,
+// 2 = sc0 sc1, 3 = sc1 nt, 4 = sc0 sc1 nt
+#ifndef OD_ST16_POLICY
+#define OD_ST16_POLICY 0
+#endif
 __device__ __forceinline__ void od_st16_nt(void* p, u32x4 r) {
+#if OD_ST16_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(r) : "memory");
+#elif OD_ST16_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(p), "v"(r) : "memory");
+#elif OD_ST16_POLICY == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 0" ::"v"(p), "v"(r) : "memory");
+#elif OD_ST16_POLICY == 4
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 0" ::"v"(p), "v"(r) : "memory");
+#else
     asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(p), "v"(r) : "memory");
+#endif
 }
 #endif
 

@@ -56,3 +56,29 @@ def test_library_reports_its_source_hash():
     assert len(sha) == 16 and all(c in "0123456789abcdef" for c in sha)
     tree = subprocess.check_output(["bash", os.path.join(os.path.dirname(_lib.DEFAULT_SO), "csrc", "source_sha.sh")], text=True).strip()
     assert sha == tree, "the in-tree library is stale: run csrc/build.sh"
+
+
+def test_power_sampler_energy(bench_mod, tmp_path):
+    """joules_per_step: the hwmon energy counter's delta where the board has one, otherwise the 100 Hz power trace integrated over the timed
+    region (trapezoid, the first / last reading held to the region's ends); None — never a made-up number — without readings."""
+    bench, _ = bench_mod
+    ps = bench.PowerSampler.__new__(bench.PowerSampler)
+    ps.period, ps.dir = 0.01, None
+    ps.samples, ps.times = [], []
+    ps.t_enter, ps.t_exit, ps.e_enter, ps.e_exit = 10.0, 12.0, None, None
+    assert ps.joules()[0] is None
+    # a trace: 1000 W for the first second, ramping to 1400 W over the second one
+    ps.times = [10.0 + 0.01 * i for i in range(1, 200)]
+    ps.samples = [((1000.0 if t <= 11.0 else 1000.0 + 400.0 * (t - 11.0)), 2000.0) for t in ps.times]
+    j, src = ps.joules()
+    assert j == pytest.approx(1000.0 + 1200.0, rel=2e-3) and "integral" in src
+    # an energy counter wins over the trace
+    ps.e_enter, ps.e_exit = 5.0e6, 2.405e9
+    j, src = ps.joules()
+    assert j == pytest.approx(2400.0) and "energy1_input" in src
+    # a hwmon directory without the files: every field None
+    hw = tmp_path / "hwmon0"
+    hw.mkdir()
+    ps2 = bench.PowerSampler.__new__(bench.PowerSampler)
+    ps2.dir = str(hw)
+    assert ps2._num("energy1_input") is None and ps2._read() == (None, None)
