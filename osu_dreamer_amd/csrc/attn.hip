@@ -692,22 +692,31 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
 }
 
 #ifndef OD_FWD16X
-#define OD_FWD16X 0       // 1 (A/B build, round 6): bf16 / hd 64 / pre-multiplied q runs flash_fwd16x_kernel — flash_fwd32_kernel's structure on 16x16x32 tiles
+#define OD_FWD16X 1       // bf16 / IEEE-half operands, hd 64, pre-multiplied q: flash_fwd16x_kernel — flash_fwd32_kernel's structure on 16x16x32 tiles (0: flash_fwd32_kernel)
+#endif
+#ifndef OD_FWD16X_NQT
+#define OD_FWD16X_NQT 2   // 16-query tiles per wave (4: a tie, 7.39-7.48 ms; 1: 8.87; 3: 7.85 — profiles/r06h_ab_fwd16x_nqt_sampler.txt)
+#endif
+#ifndef OD_FWD16X_MIN_L
+#define OD_FWD16X_MIN_L 2048   // sequences from this length on run flash_fwd16x_kernel, shorter ones flash_fwd32_kernel (the emulator build lowers it: both are tested)
 #endif
 #if OD_FWD16X
 // flash_fwd32_kernel's STRUCTURE — buffer-addressed asm LDS-DMA (rows past L read as zero), compile-time stage addresses (loop unrolled by two),
 // the lazy log2-domain reference with the running row SUM as the overflow guard (no per-tile row maximum), scalar row sums — on
-// v_mfma_f32_16x16x32_bf16 tiles in flash_fwd_kernel's formulation (S^T = K Q^T: a softmax row is an accumulator column; P^T feeds O^T += V^T P^T
+// v_mfma_f32_16x16x32 tiles in flash_fwd_kernel's formulation (S^T = K Q^T: a softmax row is an accumulator column; P^T feeds O^T += V^T P^T
 // through a k-permutation the V transpose reads reproduce).  Per wave and 64-key tile: 32 MFMAs of 16 cycles where the 32x32x16 form issues
-// 16 of 32, the same 8 + 16 LDS fragment reads, the same exponentials.  VERDICT r5 item 4: "build the thing, or retire the question with a
-// measurement" — profiles/r06g_ab_fwd16x.txt.  bf16, head_dim 64, q pre-multiplied by scale * log2(e).
-template <int NW>
+// 16 of 32, the same 8 + 16 LDS fragment reads, the same exponentials — and 128 registers (four waves per SIMD; the 32x32 form: 158, three).
+// Round 6 ("build the thing, or retire the question with a measurement"): 7.64 against 8.01 ms per call at B = 32 x L = 8192 on
+// one box, 311.6 against 314.6 ms per step (profiles/r06g_ab_fwd16x.txt) — the 16x16x32 MFMA draws ~7 % less per FLOP on a board whose power cap
+// sets the clock (profiles/r03u_mfma_power.txt), which the issue model of round 2 (twice the MFMA issue slots: -12 %) did not know about.
+// bf16 or IEEE-half operands (TA), head_dim 64, q pre-multiplied by scale * log2(e).
+template <int NW, int NQT, class TA>
 __global__ __launch_bounds__(64 * NW, 2) void flash_fwd16x_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                                   const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
                                                                   float* __restrict__ lse, int B, int H, int L) {
-    using T = bf16_t;
+    using T = TA;                                   // the MFMA operand type: q, k, v hold bf16 or IEEE half (same 16-bit containers); o is bf16
     using St = Stage<bf16_t, 64>;
-    constexpr int HD = 64, NQT = 2, QB = NW * 32, STAGE = 2 * St::BYTES;
+    constexpr int HD = 64, QB = NW * 16 * NQT, STAGE = 2 * St::BYTES;
     static_assert(NW == 4, "the K / V tiles are streamed as 2 + 2 one-KiB pieces per wave");
     OD_DYN_SMEM(smem);
     const int nqt = (L + QB - 1) / QB;
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd16x_kernel(const bf16_t* 
     const int b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = od_uniform(threadIdx.x >> 6), x = lane & 15, g = lane >> 4;
     const bf16_t* qb = q + (size_t)b * L * ldq + h * HD;
-    const int q0 = qt * QB + wave * 32;
+    const int q0 = qt * QB + wave * 16 * NQT;
     const od_srd_t rk = od_make_srd(k + (size_t)b * L * ldk + h * HD, (unsigned)(((size_t)(L - 1) * ldk + HD) * 2));
     const od_srd_t rv = od_make_srd(v + (size_t)b * L * ldv + h * HD, (unsigned)(((size_t)(L - 1) * ldv + HD) * 2));
     // piece = 8 rows x 128 B, tile_off<128>'s swizzle (slot ^ (row & 7), row & 7 = lane >> 3) applied on the SOURCE column; a wave moves pieces w, w + 4
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd16x_kernel(const bf16_t* 
     for (int qi = 0; qi < NQT; qi++) {
         int row = q0 + qi * 16 + x; row = row < L ? row : L - 1;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) od_frag_load(fq[qi][s2], qb + (size_t)row * ldq + s2 * 32 + g * 8);
+        for (int s2 = 0; s2 < 2; s2++) od_frag_load(fq[qi][s2], (const TA*)(qb + (size_t)row * ldq + s2 * 32 + g * 8));
     }
     f32x4 oacc[NQT][4];
     float mref[NQT], lrun[NQT];                     // mref in log2 units (q is pre-multiplied)
@@ -1233,6 +1242,17 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
                int H, int L, float scale, hipStream_t st) {
     if constexpr (std::is_same<T, f16_t>::value) {          // half operands: q, k, v are IEEE half, o is written as bf16 (head_dim 64 only)
         static_assert(HD == 64, "the half-operand forward exists for head_dim 64");
+#if OD_FWD16X
+        static const int fwd16x_min_l_h = od_env_int("OD_FWD16X_MIN_L", OD_FWD16X_MIN_L);
+        if (PRE && L >= fwd16x_min_l_h) {
+            constexpr int NQT = OD_FWD16X_NQT;
+            const int grid = attn_grid((L + 4 * 16 * NQT - 1) / (4 * 16 * NQT), B * H);
+            OD_LAUNCH_DYN((flash_fwd16x_kernel<4, NQT, f16_t>), dim3(grid), dim3(256), (4 * Stage<bf16_t, HD>::BYTES), st, (const bf16_t*)q, ldq,
+                          (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L);
+            OD_CHECK_LAUNCH();
+            return 0;
+        }
+#endif
         constexpr int NW = 4, NQB = OD_FWD32_NQB;
         const int grid = attn_grid((L + NW * NQB * 32 - 1) / (NW * NQB * 32), B * H);
         OD_LAUNCH_DYN((flash_fwd32_kernel<NW, NQB, PRE, f16_t>), dim3(grid), dim3(64 * NW), (4 * Stage<bf16_t, HD>::BYTES), st, (const bf16_t*)q, ldq,
@@ -1244,12 +1264,18 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 #define OD_FWD32_NW 4     // waves per workgroup of the bf16 / hd 64 forward (8: one workgroup per CU, the K / V tiles staged once for 256 queries; A/B)
 #endif
 #if OD_FWD16X
-    if constexpr (std::is_same<T, bf16_t>::value && HD == 64 && PRE) {
-        const int grid = attn_grid((L + 127) / 128, B * H);
-        OD_LAUNCH_DYN((flash_fwd16x_kernel<4>), dim3(grid), dim3(256), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq,
+    // long sequences: the 16x16x32 form (7.48 against 7.80 ms at B = 32 x L = 8192); at the sampler's L = 1115 the 32x32x16 form is ahead by 1.5 %
+    // (66.7 against 65.7 ms per 50-step call: profiles/r06h_ab_fwd16x_nqt_sampler.txt).  OD_FWD16X_MIN_L moves the switch.
+    static const int fwd16x_min_l = od_env_int("OD_FWD16X_MIN_L", OD_FWD16X_MIN_L);
+    if (std::is_same<T, bf16_t>::value && HD == 64 && PRE && L >= fwd16x_min_l) {
+      if constexpr (std::is_same<T, bf16_t>::value && HD == 64 && PRE) {
+        constexpr int NQT = OD_FWD16X_NQT;
+        const int grid = attn_grid((L + 4 * 16 * NQT - 1) / (4 * 16 * NQT), B * H);
+        OD_LAUNCH_DYN((flash_fwd16x_kernel<4, NQT, bf16_t>), dim3(grid), dim3(256), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq,
                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L);
         OD_CHECK_LAUNCH();
         return 0;
+      }
     }
 #endif
     if constexpr (OD_FWD32 && std::is_same<T, bf16_t>::value && HD == 64) {

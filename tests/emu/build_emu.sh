@@ -11,7 +11,7 @@ for s in gemm rowops misc heads optim attn attn_bwd_fused style latent comm cali
   o=build/$s.o
   if [ ! -f "$o" ] || [ "$CS/$s.hip" -nt "$o" ] || [ "$CS/od_common.h" -nt "$o" ] || [ "$CS/od_tiles.h" -nt "$o" ] || [ "$CS/od_api_internal.h" -nt "$o" ] || [ ../../include/osu_dreamer_hip.h -nt "$o" ] || [ emu_hip.h -nt "$o" ]; then
     rm -f "$o"
-    /opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fPIC -DOD_EMU -DOD_GEMM_BIG_MIN_M=256 -DOD_DW_SMALL_THREADS=10 -DOD_GEMM_SMALL_TILES=6 -I. -I$CS -Wno-unused-value -c $CS/$s.hip -o $o &
+    /opt/rocm/lib/llvm/bin/clang++ -x c++ -std=c++17 -O2 -fPIC -DOD_EMU -DOD_GEMM_BIG_MIN_M=256 -DOD_DW_SMALL_THREADS=10 -DOD_GEMM_SMALL_TILES=6 -DOD_FWD16X_MIN_L=128 -I. -I$CS -Wno-unused-value -c $CS/$s.hip -o $o &
     PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
