@@ -697,6 +697,9 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
 #ifndef OD_FWD16X_NQT
 #define OD_FWD16X_NQT 2   // 16-query tiles per wave (4: a tie, 7.39-7.48 ms; 1: 8.87; 3: 7.85 — profiles/r06h_ab_fwd16x_nqt_sampler.txt)
 #endif
+#ifndef OD_FWD16X_NW
+#define OD_FWD16X_NW 4    // waves per workgroup (8: the K / V tiles staged once for 256 queries; A/B)
+#endif
 #ifndef OD_FWD16X_MIN_L
 #define OD_FWD16X_MIN_L 2048   // sequences from this length on run flash_fwd16x_kernel, shorter ones flash_fwd32_kernel (the emulator build lowers it: both are tested)
 #endif
@@ -711,13 +714,13 @@ __global__ __launch_bounds__(64 * NW, (NQB == 1 ? 2 : OD_FWD32_OCC2)) void flash
 // sets the clock (profiles/r03u_mfma_power.txt), which the issue model of round 2 (twice the MFMA issue slots: -12 %) did not know about.
 // bf16 or IEEE-half operands (TA), head_dim 64, q pre-multiplied by scale * log2(e).
 template <int NW, int NQT, class TA>
-__global__ __launch_bounds__(64 * NW, 2) void flash_fwd16x_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 1 : 2)) void flash_fwd16x_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                                   const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ o, int ldo,
                                                                   float* __restrict__ lse, int B, int H, int L) {
     using T = TA;                                   // the MFMA operand type: q, k, v hold bf16 or IEEE half (same 16-bit containers); o is bf16
     using St = Stage<bf16_t, 64>;
     constexpr int HD = 64, QB = NW * 16 * NQT, STAGE = 2 * St::BYTES;
-    static_assert(NW == 4, "the K / V tiles are streamed as 2 + 2 one-KiB pieces per wave");
+    static_assert(NW == 4 || NW == 8, "the K / V tiles are streamed as 2 + 2 (four waves) or 1 + 1 (eight waves) one-KiB pieces per wave");
     OD_DYN_SMEM(smem);
     const int nqt = (L + QB - 1) / QB;
     int qt, bh;
@@ -734,9 +737,9 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_fwd16x_kernel(const bf16_t* 
     auto dma = [&](int kt, unsigned char* st) {
         const unsigned sk = (unsigned)kt * 64u * (unsigned)ldk * 2u, sv = (unsigned)kt * 64u * (unsigned)ldv * 2u;
         od_buffer_lds16(rk, vk, sk, st + wave * 1024);
-        od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
+        if (NW == 4) od_buffer_lds16(rk, vk, sk + 32u * (unsigned)ldk * 2u, st + (wave + 4) * 1024);
         od_buffer_lds16(rv, vv, sv, st + St::BYTES + wave * 1024);
-        od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + St::BYTES + (wave + 4) * 1024);
+        if (NW == 4) od_buffer_lds16(rv, vv, sv + 32u * (unsigned)ldv * 2u, st + St::BYTES + (wave + 4) * 1024);
     };
     od_frag<T> fq[NQT][2];
 #pragma unroll
@@ -1269,9 +1272,9 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
     static const int fwd16x_min_l = od_env_int("OD_FWD16X_MIN_L", OD_FWD16X_MIN_L);
     if (std::is_same<T, bf16_t>::value && HD == 64 && PRE && L >= fwd16x_min_l) {
       if constexpr (std::is_same<T, bf16_t>::value && HD == 64 && PRE) {
-        constexpr int NQT = OD_FWD16X_NQT;
-        const int grid = attn_grid((L + 4 * 16 * NQT - 1) / (4 * 16 * NQT), B * H);
-        OD_LAUNCH_DYN((flash_fwd16x_kernel<4, NQT, bf16_t>), dim3(grid), dim3(256), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq,
+        constexpr int NQT = OD_FWD16X_NQT, NWX = OD_FWD16X_NW;
+        const int grid = attn_grid((L + NWX * 16 * NQT - 1) / (NWX * 16 * NQT), B * H);
+        OD_LAUNCH_DYN((flash_fwd16x_kernel<NWX, NQT, bf16_t>), dim3(grid), dim3(64 * NWX), (4 * Stage<T, HD>::BYTES), st, (const bf16_t*)q, ldq,
                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, B, H, L);
         OD_CHECK_LAUNCH();
         return 0;
