@@ -179,6 +179,23 @@ class GradBucketReducer:
         self._done.clear()
         self.bucket_log = self.bucket_log[-64:]
 
+    def global_status(self, local: torch.Tensor) -> torch.Tensor:
+        """The ranks' attention-backward status words OR-ed into one device word every rank agrees on: a rank whose fused backward
+        failed has already sent its incomplete / NaN gradients into the all-reduce, so EVERY rank must poison its norm and skip the update —
+        with a rank-local word the healthy ranks would step on them and the replicas diverge.  `local`: this rank's int32[1] word.  One
+        4-byte all-reduce per step on the compute stream (which has just waited for the bucket exchange: the communicator's collectives stay
+        ordered).  Returns an int32[1] tensor: 0, or 4 = "some rank's attention backward failed" (this rank's own code stays in its workspace)."""
+        if getattr(self, "_st_f", None) is None or self._st_f.device != local.device:
+            self._st_f = torch.zeros(1, dtype=torch.float32, device=local.device)
+            self._st_i = torch.zeros(1, dtype=torch.int32, device=local.device)
+        self._st_f.copy_((local != 0).to(torch.float32))
+        if self.comm is not None:
+            self.comm.allreduce_mean_(self._st_f)
+        else:
+            dist.all_reduce(self._st_f, op=dist.ReduceOp.SUM, group=self.pg)
+        self._st_i.copy_((self._st_f > 0).to(torch.int32) * 4)
+        return self._st_i
+
     def exposed_ms(self, reset: bool = True) -> List[float]:
         """Per step since the last reset: milliseconds the compute stream spent waiting for the gradient exchange (synchronises)."""
         torch.cuda.synchronize()

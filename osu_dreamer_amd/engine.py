@@ -499,6 +499,10 @@ class DenoiserEngine:
         """Device address of the sticky error word of the fused attention backward the last `backward` used (0: none ran)."""
         return self._attn_ws.err_ptr() if self._attn_ws is not None else 0
 
+    def attn_status_view(self) -> torch.Tensor:
+        """The same word as an int32[1] tensor (data-parallel steps reduce it over the ranks)."""
+        return self._attn_ws.err_view()
+
     ATTN_STATUS = {1: "a launch left jobs unprocessed (an XCD ran none of its workgroups): gradients incomplete",
                    2: "a launch with another (B, H, L) than the workspace's earlier launches was refused",
                    3: "a chain wait ran out of time (the predecessor's write never came; OD_FB_CHAIN_TIMEOUT_MS): dq is NaN"}

@@ -303,6 +303,11 @@ class FusedAttnBwdWorkspace:
         """Device address of the sticky error word: ops.sqnorm / ops.adamw_ema fold it into the step without a host round trip."""
         return self.buf.data_ptr() + int(_lib.lib().cdll.od_flash_attn_bwd_fused_err_offset())
 
+    def err_view(self) -> torch.Tensor:
+        """The sticky error word as an int32[1] tensor (a view of the workspace): what a data-parallel step reduces over the ranks."""
+        off = int(_lib.lib().cdll.od_flash_attn_bwd_fused_err_offset())
+        return self.buf[off:off + 4].view(torch.int32)
+
     def status(self) -> int:
         """The sticky error word (0 = every launch processed all of its jobs; 1 / 2 / 3: see the header).  Waits for the current stream."""
         import ctypes

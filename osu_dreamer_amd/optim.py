@@ -58,6 +58,11 @@ class FusedAdamWEMA(torch.optim.Optimizer):
         # (DenoiserEngine.check_attn_status) — no host synchronisation here
         eng = getattr(model, "_engine", None)
         status = eng.attn_status_ptr() if eng is not None else 0
+        if status and reducer is not None and reducer.world > 1:
+            # data parallel: the word every rank acts on is the OR over the ranks (GradBucketReducer.global_status) — a failed rank's gradients
+            # are in everybody's all-reduced arena already
+            self._global_status = reducer.global_status(eng.attn_status_view())
+            status = self._global_status.data_ptr()
         if clip > 0 or status:
             self.gnorm_sq.zero_()
             ops.sqnorm(g, self.gnorm_sq, status)
@@ -77,6 +82,10 @@ class FusedAdamWEMA(torch.optim.Optimizer):
         eng = getattr(self.model, "_engine", None)
         if eng is not None:
             eng.check_attn_status()
+        gs = getattr(self, "_global_status", None)
+        if gs is not None and int(gs.item()) != 0:
+            raise RuntimeError("od_flash_attn_bwd_fused failed on another rank of this data-parallel job (status 4): the optimizer steps since then "
+                               "were skipped on every rank")
 
     # flat-state checkpointing (resume via --ckpt-path)
     def state_dict(self):

@@ -345,3 +345,64 @@ def test_torch_ddp_wrapper_averages_the_arena_gradients(tmp_path, bucket_view):
             # the averaged .grad into the arena before it reads it (DiffusionModel.adopt_grads)
             assert not any(o["arena_is_grad"])
         assert all(a == 0.0 for a in o["adopted_diff"]), o["adopted_diff"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# A failed attention backward on ONE rank.  Its incomplete / NaN gradients are already in everybody's all-reduced arena, so the
+# status word every rank's optimizer acts on is the OR over the ranks (GradBucketReducer.global_status): all ranks skip the update (weights
+# bit-identical to before, and still identical across ranks) and all ranks raise at their next check — the failing one with its own code,
+# the healthy one with "another rank".
+def _failed_rank_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      OD_ATTN_BWD_FUSED="1", OD_FB_CHAIN_TIMEOUT_MS="50")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import denoiser_oracle as O
+    from osu_dreamer_amd import _lib
+    from osu_dreamer_amd.ddp import GradBucketReducer
+    from kernel_backend import EMU_SO
+    from test_model_parity import make_trainer
+    _lib.use_library(EMU_SO)
+    d = O.Dims(global_cond_dim=64, backbone_dim=128, n_heads=2, head_dim=64, depth=2, expand=2, radius=1, u_head_dim=16)
+    P = O.init_params(d, seed=11)
+    tr = make_trainer(d, P, torch.device("cpu"))
+    model = tr.diffusion
+    model.compute_dtype = torch.bfloat16
+    red = GradBucketReducer(model)
+    red.broadcast_parameters(0)
+    data = O.synthetic_batch(d, 2, 230, seed=12 + rank)
+    opt = tr.configure_optimizers()["optimizer"]
+    opt.max_grad_norm = 1.0
+
+    def step():
+        opt.zero_grad()
+        loss, _ = tr(model, data["h"], data["z"], data["s"], None, t=data["t"], x0=data["x0"])
+        loss.backward()
+        opt.step()
+    step()
+    opt.check_device_status()                                  # healthy step on both ranks
+    good = model.arena.data.detach().clone()
+    if rank == 1:                                              # damaged write numbers in every running tile of rank 1's workspace
+        ws = model.engine._attn_ws
+        ws.buf[256:ws.zero_bytes].view(torch.int32).fill_(5)
+    step()
+    raised = ""
+    try:
+        opt.check_device_status()
+    except RuntimeError as e:
+        raised = str(e)
+    torch.save({"skipped": bool(torch.equal(model.arena.data, good)), "p": model.arena.data.clone(), "raised": raised,
+                "gnorm_nan": bool(torch.isnan(opt.gnorm_sq).all())}, os.path.join(out_dir, f"fail{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_failed_attention_backward_on_one_rank_stops_every_rank(tmp_path):
+    from kernel_backend import build_emu
+    build_emu()
+    mp.spawn(_failed_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "fail0.pt"), torch.load(tmp_path / "fail1.pt")
+    assert r0["skipped"] and r1["skipped"] and r0["gnorm_nan"] and r1["gnorm_nan"]
+    assert torch.equal(r0["p"], r1["p"])                        # the replicas did not diverge
+    assert "another rank" in r0["raised"] and "status 3" in r1["raised"]
