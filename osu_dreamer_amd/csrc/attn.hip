@@ -1292,9 +1292,12 @@ int launch_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, in
 #ifndef OD_FWD_X3P
 #define OD_FWD_X3P 1      // fp32-as-3-x-bf16, head_dim 64: the kernel that splits K / V once per tile at staging time (0 = the generic kernel, for A/B)
 #endif
+#ifndef OD_X3P_NQT
+#define OD_X3P_NQT 2      // 16-query tiles per wave of the fp32-as-3-x-bf16 forward (1: A/B, profiles/r06l_ab_x3p_nqt.txt)
+#endif
     if constexpr (OD_FWD_X3P && std::is_same<T, f32x3_t>::value && HD == 64) {
-        const int grid = attn_grid((L + 4 * 32 - 1) / (4 * 32), B * H);
-        OD_LAUNCH_DYN((flash_fwd_x3p_kernel<4, PRE, 2>), dim3(grid), dim3(256), (2 * 4 * 64 * 128), st, (const float*)q, ldq, (const float*)k, ldk,
+        const int grid = attn_grid((L + 4 * 16 * OD_X3P_NQT - 1) / (4 * 16 * OD_X3P_NQT), B * H);
+        OD_LAUNCH_DYN((flash_fwd_x3p_kernel<4, PRE, OD_X3P_NQT>), dim3(grid), dim3(256), (2 * 4 * 64 * 128), st, (const float*)q, ldq, (const float*)k, ldk,
                       (const float*)v, ldv, (float*)o, ldo, lse, B, H, L, scale);
         OD_CHECK_LAUNCH();
         return 0;
