@@ -129,6 +129,13 @@ int od_rmsnorm_gate_residual(int dtype, const void* x, int ldx, const void* h, i
 int od_rmsnorm_gate_residual_film(int dtype, const void* x, int ldx, const void* h, int ldh, const float* ssg_a, void* xo, int ldxo,
                                   float* inv_a, const float* ssg_b, const void* cl, int ldcl, int cl_bcast, void* h2, int ldh2,
                                   float* inv_b, int B, int L, int C, float eps, void* stream);
+/* the same AND the depthwise Conv1d that opens the SwiGLU branch, in one pass (round 6): y = dwconv_k(h2) + conv_b with h2 as above (no cl),
+ * h2 rounded to dtype before the taps — bit-identical to od_rmsnorm_gate_residual_film followed by od_dwconv.  h2 may be NULL (not kept);
+ * xo must not alias x or h (a wave recomputes the ksize/2 frames either side of its run from them).  C <= 512, ksize 3 / 5 / 7 / 9.
+ * replaces: backbone.py:78-86 + common/swiglu.py:20 (proj_vg's depthwise conv). */
+int od_rmsnorm_gate_residual_film_dwconv(int dtype, const void* x, int ldx, const void* h, int ldh, const float* ssg_a, void* xo, int ldxo,
+                                         float* inv_a, const float* ssg_b, void* h2, int ldh2, float* inv_b, const float* conv_w,
+                                         const float* conv_b, void* y, int ldy, int B, int L, int C, int ksize, float eps, void* stream);
 /* dh = rms_norm_bwd(dy*gate); dssg[b][2C:3C] += sum dy*hhat.  (dy itself is the residual gradient.) */
 int od_rmsnorm_gate_residual_bwd(int dtype, const void* h, int ldh, const float* inv_rms, const float* ssg,
                                  const void* dy, int lddy, void* dh, int lddh, float* dssg, int B, int L, int C,

@@ -226,6 +226,100 @@ __global__ __launch_bounds__(256) void rmsnorm_gate_res_film_kernel(const T* __r
     }
 }
 
+// fused triple (forward, round 6): the pair above AND the depthwise Conv1d that opens the SwiGLU branch (swiglu.py:20): a wave walks a RUN of
+// consecutive frames of one batch row (a lane = 8 channels, as everywhere here), forms xo / h2 frame by frame and keeps the last KS rows of h2 in
+// a register window (the dwconv kernel's sliding window): y[l] = bias + sum_j w[j] h2[l - R + j] leaves as soon as frame l + R exists.  The R
+// frames either side of the run are recomputed (not stored): 2 R / RUN more reads of x and h.  h2 is rounded to the tensor type before it
+// enters the window, and the taps are summed in dwconv_kernel's order: the results are bit-identical to od_rmsnorm_gate_residual_film followed
+// by od_dwconv.  h2 may be NULL (inference: nothing reads it again); training keeps it for the conv's weight gradient.  C <= 512.
+template <class T, int KS, int RUN>
+__global__ __launch_bounds__(256) void rmsnorm_gate_res_film_dwconv_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ h, int ldh,
+                                                                           const float* __restrict__ ssg_a, T* __restrict__ xo, int ldxo,
+                                                                           float* __restrict__ inv_a, const float* __restrict__ ssg_b,
+                                                                           T* __restrict__ h2, int ldh2, float* __restrict__ inv_b,
+                                                                           const float* __restrict__ cw, const float* __restrict__ cb,
+                                                                           T* __restrict__ y, int ldy, int B, int L, int C, float eps) {
+    constexpr int R = KS / 2;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int l0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RUN;
+    if (l0 >= L) return;
+    const int c = lane * 8;
+    const bool act = c < C;
+    float gate[8], sc[8], sh[8], wv[8][KS], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        gate[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f; bv[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; j++) wv[e][j] = 0.f;
+    }
+    if (act) {
+        od_ld8(ssg_a + (size_t)b * 3 * C + 2 * C + c, gate);
+        od_ld8(ssg_b + (size_t)b * 3 * C + c, sc);
+        od_ld8(ssg_b + (size_t)b * 3 * C + C + c, sh);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            bv[k] = cb[c + k];
+#pragma unroll
+            for (int j = 0; j < KS; j++) wv[k][j] = cw[(size_t)(c + k) * KS + j];
+        }
+    }
+    float win[KS][8];
+#pragma unroll
+    for (int j = 0; j < KS; j++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) win[j][e] = 0.f;
+    const int lend = l0 + RUN < L ? l0 + RUN : L;                  // frames [l0, lend) are this wave's
+    for (int l = l0 - R; l < lend + R; l++) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) win[KS - 1][e] = 0.f;          // frames outside the sequence: the conv's zero padding
+        if (l >= 0 && l < L) {                                     // (wave-uniform)
+            const long m = (long)b * L + l;
+            const bool own = l >= l0 && l < lend;
+            float v[1][8], o[8];
+            load_row<T, 1>(h + m * ldh, C, lane, v);
+            const float inv = rsqrtf(row_sumsq<1>(v) / (float)C + eps);
+            if (act) {
+                od_ld8(x + m * ldx + c, o);
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] += v[0][e] * inv * gate[e];
+                if (own) od_st8(xo + m * ldxo + c, o);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[0][e] = od_round_to<T>(o[e]);
+            }
+            const float inv2 = rsqrtf(row_sumsq<1>(v) / (float)C + eps);
+            if (own && lane == 0) {
+                if (inv_a) inv_a[m] = inv;
+                if (inv_b) inv_b[m] = inv2;
+            }
+            if (act) {
+                float hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) hv[e] = v[0][e] * inv2 * (1.f + sc[e]) + sh[e];
+                if (own && h2) od_st8(h2 + m * ldh2 + c, hv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) win[KS - 1][e] = od_round_to<T>(hv[e]);
+            }
+        }
+        const int lc = l - R;                                      // the window now holds frames lc - R .. lc + R
+        if (lc >= l0 && lc < lend && act) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float s = bv[k];
+#pragma unroll
+                for (int j = 0; j < KS; j++) s += wv[k][j] * win[j][k];
+                o[k] = s;
+            }
+            od_st8(y + ((size_t)b * L + lc) * ldy + c, o);
+        }
+#pragma unroll
+        for (int j = 0; j < KS - 1; j++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) win[j][e] = win[j + 1][e];
+    }
+}
+
 template <class T, int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_gate_res_bwd_kernel(const T* __restrict__ h, int ldh, const float* __restrict__ inv_rms,
                                                                    const float* __restrict__ ssg, const T* __restrict__ dy, int lddy,
@@ -834,6 +928,25 @@ extern "C" int od_rmsnorm_gate_residual_film(int dtype, const void* x, int ldx, 
     DISPATCH_T_NCH(dtype, nch_for(C),
         OD_LAUNCH((rmsnorm_gate_res_film_kernel<T_, N_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, (const T_*)h, ldh,
                   ssg_a, (T_*)xo, ldxo, inv_a, ssg_b, (const T_*)cl, ldcl, cl_bcast, (T_*)h2, ldh2, inv_b, B, L, C, eps));
+    OD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int od_rmsnorm_gate_residual_film_dwconv(int dtype, const void* x, int ldx, const void* h, int ldh, const float* ssg_a, void* xo,
+                                                    int ldxo, float* inv_a, const float* ssg_b, void* h2, int ldh2, float* inv_b,
+                                                    const float* conv_w, const float* conv_b, void* y, int ldy, int B, int L, int C,
+                                                    int ksize, float eps, void* stream) {
+    if (C % 8 || ldx % 8 || ldh % 8 || ldxo % 8 || (h2 && ldh2 % 8) || ldy % 8) return OD_ERR_ALIGN;
+    if (C > 512 || (ksize != 3 && ksize != 5 && ksize != 7 && ksize != 9)) return OD_ERR_UNSUPPORTED;
+    if (!x || !h || !xo || !y || !conv_w || !conv_b || xo == x || xo == h) return OD_ERR_ARG;       // the halo frames re-read x and h: xo must not alias them
+    constexpr int RUN = 32;
+    dim3 grid((unsigned)((L + 4 * RUN - 1) / (4 * RUN)), (unsigned)B);
+#define FD_GO2(T_, KS_) OD_LAUNCH((rmsnorm_gate_res_film_dwconv_kernel<T_, KS_, RUN>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, \
+                   (const T_*)h, ldh, ssg_a, (T_*)xo, ldxo, inv_a, ssg_b, (T_*)h2, ldh2, inv_b, conv_w, conv_b, (T_*)y, ldy, B, L, C, eps)
+#define FD_GO(KS_) do { if (dtype == OD_BF16) FD_GO2(bf16_t, KS_); else if (dtype == OD_F32) FD_GO2(float, KS_); else return OD_ERR_UNSUPPORTED; } while (0)
+    if (ksize == 5) FD_GO(5); else if (ksize == 3) FD_GO(3); else if (ksize == 7) FD_GO(7); else FD_GO(9);
+#undef FD_GO
+#undef FD_GO2
     OD_CHECK_LAUNCH();
     return 0;
 }

@@ -25,6 +25,8 @@ import torch
 from . import det, ops
 from ._lib import OD_ACT_NONE, OD_ACT_SILU
 
+OD_FUSE_FILM_DWCONV_DEFAULT = "0"       # (see DenoiserEngine.pred)
+
 FP32_EPS = float(torch.finfo(torch.float32).eps)   # nn.RMSNorm(eps=None), common/attn.py:71-72
 
 
@@ -271,10 +273,21 @@ class DenoiserEngine:
             # --- gate + residual of the attention branch and norm + FiLM of the feed-forward branch, one pass
             x_mid = self.lbuf("x_mid", i, (M, D))
             h2 = self.lbuf("h2", i, (M, D))
-            ops.rmsnorm_gate_residual_film(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), ssg2, None, False, h2,
-                                           self.lbuf("inv3", i, (M,), f32), B, L)
+            # (OD_FUSE_FILM_DWCONV=1: those two AND the SwiGLU branch's depthwise conv as one kernel — bit-identical, 0.3 ms per step at the
+            #  bench shape: profiles/r06q_ab_film_dwconv.txt; large training shapes only: a wave walks 32 frames)
+            fuse_dw = (self.radius > 0 and D <= 512 and self.train and M >= 32768 and x.data_ptr() != x_mid.data_ptr()
+                       and os.environ.get("OD_FUSE_FILM_DWCONV", OD_FUSE_FILM_DWCONV_DEFAULT) == "1")
+            if fuse_dw:
+                hdw = self.lbuf("hdw", i, (M, D))
+                ops.rmsnorm_gate_residual_film_dwconv(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), ssg2, h2, self.lbuf("inv3", i, (M,), f32),
+                                                      self.P(p + "ffn.proj_vg.0.weight"), self.P(p + "ffn.proj_vg.0.bias"), hdw, B, L, self.ksize)
+            else:
+                ops.rmsnorm_gate_residual_film(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), ssg2, None, False, h2,
+                                               self.lbuf("inv3", i, (M,), f32), B, L)
             # --- feed-forward branch (backbone.py:82-86, swiglu.py:27-32)
-            if self.radius > 0:
+            if fuse_dw:
+                pass
+            elif self.radius > 0:
                 hdw = self.lbuf("hdw", i, (M, D))
                 ops.dwconv(h2, self.P(p + "ffn.proj_vg.0.weight"), self.P(p + "ffn.proj_vg.0.bias"), hdw, B, L, self.ksize)
             else:

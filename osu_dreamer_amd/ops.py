@@ -218,6 +218,15 @@ def rmsnorm_gate_residual_film(x, h, ssg_a, xo, inv_a, ssg_b, cl, cl_bcast, h2, 
                                              _p(h2), _ld(h2), _p(inv_b), B, L, x.shape[1], eps, _stream(x))
 
 
+def rmsnorm_gate_residual_film_dwconv(x, h, ssg_a, xo, inv_a, ssg_b, h2, inv_b, conv_w, conv_b, y, B, L, ksize, eps=1e-6):
+    """rmsnorm_gate_residual_film (no cl) and the depthwise conv of the SwiGLU branch in one pass: y = dwconv(h2) + b.  h2 may be None."""
+    _f32(ssg_a, ssg_b, inv_a, inv_b, conv_w, conv_b)
+    assert xo.data_ptr() != x.data_ptr() and xo.data_ptr() != h.data_ptr()
+    _lib.lib().od_rmsnorm_gate_residual_film_dwconv(dt_code(x.dtype), _p(x), _ld(x), _p(h), _ld(h), _p(ssg_a), _p(xo), _ld(xo), _p(inv_a),
+                                                    _p(ssg_b), _p(h2), _ld(h2) if h2 is not None else 0, _p(inv_b), _p(conv_w), _p(conv_b),
+                                                    _p(y), _ld(y), B, L, x.shape[1], ksize, eps, _stream(x))
+
+
 def rmsnorm_gate_residual_bwd(h, inv_rms, ssg, dy, dh, dssg, B, L):
     C = h.shape[1]
     _f32(ssg, inv_rms, dssg)

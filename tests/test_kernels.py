@@ -926,3 +926,36 @@ def test_det_api_refuses_what_it_cannot_do(dev):
     dW = torch.zeros(16, 8, device=dev)
     ops.gemm_tn(G, A, dW)                                                      # mode off: lands in dW directly
     assert rel_l2(dW, G.cpu().t() @ A.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L,C,ks", [(2, 77, 64, 5), (1, 33, 128, 3), (3, 130, 512, 5), (2, 9, 40, 9), (1, 200, 512, 7)])
+def test_rmsnorm_gate_residual_film_dwconv_equals_the_two_kernels(dev, dtype, B, L, C, ks):
+    """The fused triple of round 6 (gate + residual of the attention branch, norm + FiLM of the feed-forward branch, the SwiGLU branch's depthwise
+    conv: backbone.py:78-86 + swiglu.py:20) against od_rmsnorm_gate_residual_film followed by od_dwconv: identical xo, h2, inverse RMS values
+    and conv output (bit for bit in bf16) — runs shorter and longer than a wave's 32 frames, ragged ends, channel counts below a wave's 512; and with h2 = None."""
+    g = torch.Generator().manual_seed(40 + L)
+    M = B * L
+    x, h = mk((M, C), g, dev, dtype), mk((M, C), g, dev, dtype)
+    ssg_a, ssg_b = mk((B, 3 * C), g, dev, scale=0.5), mk((B, 3 * C), g, dev, scale=0.5)
+    cw, cb = mk((C, ks), g, dev, scale=0.4), mk((C,), g, dev, scale=0.1)
+    xo1, h21, y1 = (torch.zeros(M, C, dtype=dtype, device=dev) for _ in range(3))
+    ia1, ib1 = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    ops.rmsnorm_gate_residual_film(x, h, ssg_a, xo1, ia1, ssg_b, None, False, h21, ib1, B, L)
+    ops.dwconv(h21, cw, cb, y1, B, L, ks)
+    xo2, h22, y2 = (torch.full((M, C), 7.0, dtype=dtype, device=dev) for _ in range(3))
+    ia2, ib2 = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    ops.rmsnorm_gate_residual_film_dwconv(x, h, ssg_a, xo2, ia2, ssg_b, h22, ib2, cw, cb, y2, B, L, ks)
+    def same(a, b_):
+        # bf16 tensors: bit for bit (on the emulator fp32 too).  fp32 on the GPU: hipcc contracts the two kernels' multiply-adds differently
+        # (fma formation), so the fp32 results agree to rounding, not to the bit
+        if dtype == torch.bfloat16 or dev.type == "cpu":
+            return torch.equal(a.cpu(), b_.cpu())
+        return rel_l2(a, b_.cpu()) < 1e-6
+    for a, b_ in ((xo1, xo2), (h21, h22), (y1, y2)):
+        assert same(a, b_)
+    assert rel_l2(ia1, ia2.cpu()) < 1e-6 and rel_l2(ib1, ib2.cpu()) < 1e-6
+    y3 = torch.zeros(M, C, dtype=dtype, device=dev)
+    xo3 = torch.zeros(M, C, dtype=dtype, device=dev)
+    ops.rmsnorm_gate_residual_film_dwconv(x, h, ssg_a, xo3, ia2, ssg_b, None, ib2, cw, cb, y3, B, L, ks)
+    assert same(y3, y1) and same(xo3, xo1)
