@@ -939,13 +939,17 @@ extern "C" int od_rmsnorm_gate_residual_film_dwconv(int dtype, const void* x, in
     if (C % 8 || ldx % 8 || ldh % 8 || ldxo % 8 || (h2 && ldh2 % 8) || ldy % 8) return OD_ERR_ALIGN;
     if (C > 512 || (ksize != 3 && ksize != 5 && ksize != 7 && ksize != 9)) return OD_ERR_UNSUPPORTED;
     if (!x || !h || !xo || !y || !conv_w || !conv_b || xo == x || xo == h) return OD_ERR_ARG;       // the halo frames re-read x and h: xo must not alias them
-    constexpr int RUN = 32;
-    dim3 grid((unsigned)((L + 4 * RUN - 1) / (4 * RUN)), (unsigned)B);
-#define FD_GO2(T_, KS_) OD_LAUNCH((rmsnorm_gate_res_film_dwconv_kernel<T_, KS_, RUN>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, \
+    // a wave walks 32 frames (2 R / 32 of halo re-reads); launches too small to cover the chip that way (the sampler: B L = 4460) take runs of 8
+    const bool small = (long)B * ((L + 31) / 32) < 2048;
+    const int run = small ? 8 : 32;
+    dim3 grid((unsigned)((L + 4 * run - 1) / (4 * run)), (unsigned)B);
+#define FD_GO2(T_, KS_, RUN_) OD_LAUNCH((rmsnorm_gate_res_film_dwconv_kernel<T_, KS_, RUN_>), grid, dim3(256), 0, (hipStream_t)stream, (const T_*)x, ldx, \
                    (const T_*)h, ldh, ssg_a, (T_*)xo, ldxo, inv_a, ssg_b, (T_*)h2, ldh2, inv_b, conv_w, conv_b, (T_*)y, ldy, B, L, C, eps)
-#define FD_GO(KS_) do { if (dtype == OD_BF16) FD_GO2(bf16_t, KS_); else if (dtype == OD_F32) FD_GO2(float, KS_); else return OD_ERR_UNSUPPORTED; } while (0)
+#define FD_GO1(T_, KS_) do { if (small) FD_GO2(T_, KS_, 8); else FD_GO2(T_, KS_, 32); } while (0)
+#define FD_GO(KS_) do { if (dtype == OD_BF16) FD_GO1(bf16_t, KS_); else if (dtype == OD_F32) FD_GO1(float, KS_); else return OD_ERR_UNSUPPORTED; } while (0)
     if (ksize == 5) FD_GO(5); else if (ksize == 3) FD_GO(3); else if (ksize == 7) FD_GO(7); else FD_GO(9);
 #undef FD_GO
+#undef FD_GO1
 #undef FD_GO2
     OD_CHECK_LAUNCH();
     return 0;

@@ -275,11 +275,12 @@ class DenoiserEngine:
             h2 = self.lbuf("h2", i, (M, D))
             # (OD_FUSE_FILM_DWCONV=1: those two AND the SwiGLU branch's depthwise conv as one kernel — bit-identical, 0.3 ms per step at the
             #  bench shape: profiles/r06q_ab_film_dwconv.txt; large training shapes only: a wave walks 32 frames)
-            fuse_dw = (self.radius > 0 and D <= 512 and self.train and M >= 32768 and x.data_ptr() != x_mid.data_ptr()
+            fuse_dw = (self.radius > 0 and D <= 512 and x.data_ptr() != x_mid.data_ptr() and x.dtype in (torch.bfloat16, torch.float32)
                        and os.environ.get("OD_FUSE_FILM_DWCONV", OD_FUSE_FILM_DWCONV_DEFAULT) == "1")
             if fuse_dw:
                 hdw = self.lbuf("hdw", i, (M, D))
-                ops.rmsnorm_gate_residual_film_dwconv(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), ssg2, h2, self.lbuf("inv3", i, (M,), f32),
+                ops.rmsnorm_gate_residual_film_dwconv(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), ssg2, h2 if self.train else None,
+                                                      self.lbuf("inv3", i, (M,), f32),
                                                       self.P(p + "ffn.proj_vg.0.weight"), self.P(p + "ffn.proj_vg.0.bias"), hdw, B, L, self.ksize)
             else:
                 ops.rmsnorm_gate_residual_film(x, ao, ssg1, x_mid, self.lbuf("inv2", i, (M,), f32), ssg2, None, False, h2,
