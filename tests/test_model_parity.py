@@ -155,6 +155,14 @@ def test_tiny_vs_reference(dev, name):
     run_case(name, dev)
 
 
+def test_tiny_vs_reference_with_the_fused_film_conv_kernel(dev, monkeypatch):
+    """OD_FUSE_FILM_DWCONV=1 (round 6): gate + residual, norm + FiLM and the SwiGLU branch's depthwise conv run as ONE kernel, in the
+    no-grad forward, the sampler and the training step — the whole reference fixture (forward, sampler, loss, every gradient, two
+    optimizer steps) holds to the same bounds."""
+    monkeypatch.setenv("OD_FUSE_FILM_DWCONV", "1")
+    run_case("tiny_b3_l40", dev)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", GPU_ONLY)
 def test_full_width_vs_reference(name):
