@@ -95,6 +95,35 @@ def test_ddp_step_world1_equals_plain_step(pg):
     assert rel(outs[2][1], outs[0][1]) <= 3 * noise_p + 1e-4 and rel(outs[2][2], outs[0][2]) <= 3 * noise_e + 1e-4
 
 
+def test_global_status_through_rccl(pg):
+    """GradBucketReducer.global_status on the RCCL path (world size 1: the OR over one rank): 0 stays 0, any local status becomes 4, the word is
+    a device tensor the optimizer kernels can read, and the communicator keeps working for the gradient buckets afterwards.  (The two-rank
+    behaviour — a failed rank stops every rank — is tests/test_ddp_gloo.py::test_failed_attention_backward_on_one_rank_stops_every_rank.)"""
+    import bench
+    from osu_dreamer_amd.ddp import GradBucketReducer
+    dev = torch.device("cuda:0")
+    tr = bench.make_trainer(dev, seed=31)
+    red = GradBucketReducer(tr.diffusion)
+    local = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert int(red.global_status(local).item()) == 0
+    local.fill_(3)
+    g = red.global_status(local)
+    assert g.is_cuda and g.dtype == torch.int32 and int(g.item()) == 4
+    side = torch.cuda.Stream(dev)                               # the next step's first bucket goes to the side stream, behind the compute stream
+    side.wait_stream(torch.cuda.current_stream(dev))
+    x = torch.randn(1 << 16, device=dev)
+    y = x.clone()
+    with torch.cuda.stream(side):
+        red.comm.allreduce_mean_(y)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    local.zero_()
+    assert int(red.global_status(local).item()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    red.close()
+    tr.diffusion._reducer = None
+
+
 def test_bench_line_through_the_rccl_path():
     """`bench.py` as the driver's torchrun starts it at N > 1, on the one GPU the pool has: a 1-rank torchrun job (WORLD_SIZE=1 set by
     the launcher, so bench does not re-spawn) with OD_FORCE_DDP=1 — NCCL process group, RCCL communicator through the C ABI, state
